@@ -1,0 +1,191 @@
+/*
+ * metro_hip.h -- C ABI of libmetro_hip.so: the MI355X (gfx950) implementation of the MeTRo
+ * inference hot path (ResNet-v2 backbone -> 1x1 volumetric head -> soft-argmax -> mm decode).
+ *
+ * The reference (isarandi/metro-pose3d) is pure Python/TensorFlow and has NO native interface:
+ * every FLOP of this path runs inside `sess.run` of a frozen GraphDef (reference
+ * inference.py:25-27,31-43).  This header is therefore the boundary a binding would attach to
+ * in place of `tf.import_graph_def` + `Session.run`; each entry point names the reference
+ * code whose work it replaces.  Plain pointers and sizes only; no torch / TF types.
+ *
+ * Conventions:
+ *   - every function returns 0 on success or a negative MetroStatus; metro_last_error()
+ *     returns a thread-local message for the last failure on the calling thread;
+ *   - all `void* d_*` pointers are DEVICE pointers owned by the caller; the library never
+ *     allocates or frees device memory and never synchronises the stream;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - a plan is bound to the device current at creation and is not thread-safe.
+ */
+#ifndef METRO_HIP_H
+#define METRO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define METRO_ABI_VERSION 1
+
+typedef enum MetroStatus {
+    METRO_OK = 0,
+    METRO_ERR_INVALID_ARG = -1,
+    METRO_ERR_UNSUPPORTED = -2,
+    METRO_ERR_HIP = -3,
+    METRO_ERR_STATE = -4
+} MetroStatus;
+
+/* Arithmetic mode of a plan.
+ * F16: activations/weights fp16, fp32 MFMA accumulation, fp32 soft-argmax -- the reference's
+ *      default compute dtype (reference src/options.py:73, src/tfu.py:426-440).
+ * F32: activations fp32 in HBM, every contraction accumulated with v_mfma_f64_16x16x4_f64
+ *      from fp64-folded weights, fp64 soft-argmax; one rounding to fp32 per layer output.
+ *      This is the parity mode measured against the fp64 oracle (<= 1e-3 mm). */
+typedef enum MetroPrecision { METRO_PREC_F16 = 0, METRO_PREC_F32 = 1 } MetroPrecision;
+
+typedef enum MetroDType { METRO_F16 = 0, METRO_F32 = 1, METRO_F64 = 2 } MetroDType;
+
+#define METRO_MAX_JOINTS 64
+
+/* The constants a frozen graph of the reference bakes in from its flags
+ * (reference src/options.py:41,73,96,109-119; src/main.py:106-128). */
+typedef struct MetroSpec {
+    int32_t arch;                 /* 50 | 101: resnet_v2_50 / resnet_v2_101 (resnet_v2.py:272-312) */
+    int32_t stride;               /* 4 | 8 | 16 | 32: --stride-test (options.py:96)                */
+    int32_t n_joints_head;        /* J_head: head emits depth * J_head channels (volumetric.py:158) */
+    int32_t depth;                /* D = 8 (options.py:113)                                         */
+    int32_t centered_stride;      /* 1 (options.py:118)                                             */
+    int32_t proc_side;            /* 256 (options.py:41)                                            */
+    float   box_size_mm;          /* 2200 (options.py:119)                                          */
+    int32_t base_width;           /* 64 for ResNet-50/101; smaller values = toy specs for tests     */
+    int32_t precision;            /* MetroPrecision                                                 */
+    int32_t n_joints_out;         /* Jout: rows of `output` (main.py:127)                           */
+    int32_t permutation[METRO_MAX_JOINTS]; /* output row i = head joint permutation[i] (main.py:119-125) */
+} MetroSpec;
+
+typedef struct MetroPlan MetroPlan;
+
+typedef enum MetroParamKind {
+    METRO_PARAM_CONV_W = 0,   /* conv kernel, packed [c_out][kh][kw_pad][c_in_pad], BN-folded if bn_var != "" */
+    METRO_PARAM_BIAS = 1,     /* per-c_out bias: conv biases, or beta - mean*scale of the folded BN           */
+    METRO_PARAM_PRO_SCALE = 2,/* pre-activation BN as prologue: gamma / sqrt(var + 1e-5), per c_in            */
+    METRO_PARAM_PRO_SHIFT = 3 /* beta - mean * scale, per c_in                                                */
+} MetroParamKind;
+
+/* One tensor of the plan's parameter blob.  The caller fills the blob (host side, any language)
+ * from a TF-slim style variable dictionary and uploads it; see INTEGRATION.md. */
+typedef struct MetroParamInfo {
+    char    name[96];      /* plan-local name, e.g. "block3/unit_2/conv2/W"                      */
+    char    conv_var[160]; /* slim scope of the source conv ("" for prologue tensors)            */
+    char    bn_var[160];   /* slim scope of the BatchNorm folded in / used as prologue, or ""    */
+    int32_t kind;          /* MetroParamKind                                                     */
+    int32_t dtype;         /* MetroDType of the packed tensor                                    */
+    int32_t c_out, kh, kw, c_in;   /* logical conv dims (c_out = length for 1-D tensors)        */
+    int32_t kw_pad, c_in_pad;      /* packed dims; padding is zero-filled                        */
+    int64_t offset;        /* byte offset in the blob (256-byte aligned)                         */
+    int64_t bytes;
+} MetroParamInfo;
+
+typedef struct MetroLayerInfo {
+    char    name[96];
+    int32_t kind;          /* 0 input-prep, 1 conv, 2 max-pool, 3 soft-argmax partial, 4 finalize */
+    int32_t h_in, w_in, c_in, h_out, w_out, c_out, kh, kw, stride, dilation, pad_top, pad_left;
+    int32_t has_prologue, relu, has_residual, res_stride, res_offset;
+    int32_t out_dtype;     /* MetroDType of the layer output in the workspace                    */
+    int64_t out_offset;    /* byte offset of the output tensor in the workspace                  */
+    int64_t out_bytes_per_image;
+    double  flops_per_image; /* 2*MACs (convs only), SURVEY.md section 8d accounting              */
+} MetroLayerInfo;
+
+/* ---- plan life cycle: replaces tf.import_graph_def of the frozen graph
+ *      (reference inference.py:31-43) and the graph construction of
+ *      volumetric.build_inference_model (reference src/model/volumetric.py:152-216). ---- */
+int  metro_plan_create(const MetroSpec* spec, int32_t max_batch, MetroPlan** out_plan);
+int  metro_plan_destroy(MetroPlan* plan);
+int64_t metro_plan_workspace_bytes(const MetroPlan* plan);
+int64_t metro_plan_param_bytes(const MetroPlan* plan);
+int32_t metro_plan_num_params(const MetroPlan* plan);
+int  metro_plan_param_info(const MetroPlan* plan, int32_t index, MetroParamInfo* out);
+int32_t metro_plan_num_layers(const MetroPlan* plan);
+int  metro_plan_layer_info(const MetroPlan* plan, int32_t index, MetroLayerInfo* out);
+double metro_plan_flops_per_image(const MetroPlan* plan);
+/* Binds the uploaded parameter blob (device pointer, metro_plan_param_bytes() long). */
+int  metro_plan_bind_params(MetroPlan* plan, const void* d_param_blob);
+
+/* ---- the hot path: replaces sess.run(poses_tensor) (reference inference.py:25-27), i.e.
+ *      architectures.resnet (architectures.py:24-35) -> net_output_to_heatmap_and_coords
+ *      (volumetric.py:227-235) -> heatmap_to_metric (volumetric.py:303-306) -> root_relative
+ *      (tfu3d.py:23-25) -> tf.gather(permutation) (main.py:127).
+ *      d_images_nhwc: fp32 [n,256,256,3] in [0,1];  d_poses_out: fp32 [n,Jout,3] in mm. ---- */
+int  metro_forward(MetroPlan* plan, const float* d_images_nhwc, int32_t n, float* d_poses_out,
+                   void* d_workspace, void* stream);
+/* Same, stopping after layer `last_layer` (inclusive) so tests can read that layer's output at
+ * MetroLayerInfo.out_offset in the workspace.  d_poses_out may be NULL if the finalize layer
+ * is not reached. */
+int  metro_forward_upto(MetroPlan* plan, const float* d_images_nhwc, int32_t n,
+                        float* d_poses_out, void* d_workspace, void* stream,
+                        int32_t last_layer);
+
+/* ---- per-layer timing on the launch stream (HIP events around every launch; this is what
+ *      bench.py's roofline object is computed from).  ms_out[i] accumulates layer i's time. ---- */
+int  metro_forward_timed(MetroPlan* plan, const float* d_images_nhwc, int32_t n,
+                         float* d_poses_out, void* d_workspace, void* stream,
+                         float* ms_out /* [num_layers] host */);
+
+/* ---- single-kernel entry points (parity tests call these through ctypes) ---- */
+
+/* Implicit-GEMM convolution over NHWC (replaces slim.conv2d / conv2d_same call sites:
+ * reference resnet_v2.py:123-136,219-220,233-236; resnet_utils.py:82-135).  Generic over
+ * kernel size, stride, dilation and asymmetric TF padding; optional per-input-channel
+ * scale/shift+ReLU prologue (pre-activation BN, resnet_v2.py:119,229) and
+ * bias / ReLU / strided-shifted residual epilogue (resnet_v2.py:113-121,138). */
+typedef struct MetroConvDesc {
+    int32_t n, h_in, w_in, c_in;
+    int32_t in_pix_stride;      /* elements between consecutive input pixels (>= c_in)      */
+    int32_t h_out, w_out, c_out;
+    int32_t kh, kw, stride, dilation;
+    int32_t pad_top, pad_left;  /* input row = ho*stride - pad_top + r*dilation             */
+    int32_t has_prologue;       /* requires kh == kw == 1 and no padding                    */
+    int32_t relu;
+    int32_t has_residual;
+    int32_t res_h, res_w;       /* spatial dims of the residual tensor [n,res_h,res_w,c_out] */
+    int32_t res_stride, res_offset; /* residual pixel = (ho*res_stride+res_offset, wo*...)  */
+    int32_t out_dtype;          /* MetroDType: F16/F32 (fast kernel), F32 (precise kernel)  */
+} MetroConvDesc;
+
+/* fp16 operands, fp32 MFMA accumulate (v_mfma_f32_32x32x16_f16).  Weights [c_out][kh*kw*c_in]
+ * fp16, bias fp32[c_out], prologue scale/shift fp16[c_in], residual fp16. c_in % 8 == 0. */
+int  metro_conv_f16(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
+                    const void* d_pro_scale, const void* d_pro_shift, const void* d_residual,
+                    void* d_out, void* stream);
+/* fp32 activations, fp64 weights/bias/prologue, v_mfma_f64_16x16x4_f64 accumulate, fp32 out. */
+int  metro_conv_f64acc(const MetroConvDesc* d, const float* d_in, const double* d_w,
+                       const double* d_bias, const double* d_pro_scale,
+                       const double* d_pro_shift, const float* d_residual, float* d_out,
+                       void* stream);
+
+/* fp32 NHWC [n,side,side,3] -> zero-bordered fp16 [n,side+6,side+8,4] (the stem's explicit
+ * pad-3 of reference resnet_utils.py:125-135 materialised once; channel 3 is zero). */
+int  metro_prep_input_f16(const float* d_images, int32_t n, int32_t side, void* d_out, void* stream);
+
+/* 3x3 stride-2 max-pool over a ZERO-padded (1,1) input (reference resnet_utils.py:177-185).
+ * dtype METRO_F16 or METRO_F32; c % 8 == 0 (f16) / c % 4 == 0 (f32). */
+int  metro_maxpool3x3s2_zeropad(const void* d_in, void* d_out, int32_t n, int32_t h_in,
+                                int32_t w_in, int32_t c, int32_t dtype, void* stream);
+
+/* Soft-argmax over the (H,W,D) volume per joint from fp32 NHWC logits [n,side,side,depth*J]
+ * (channel = d*J + j), then mm decode, root-relative and joint permutation (reference
+ * volumetric.py:227-235,288-306; tfu.py:466-499; tfu3d.py:23-25; main.py:127).
+ * d_partials: scratch of metro_softargmax_scratch_bytes(); accumulate in fp32 (precise=0) or
+ * fp64 (precise=1). */
+int64_t metro_softargmax_scratch_bytes(int32_t n, int32_t side, int32_t n_joints_head);
+int  metro_softargmax(const float* d_logits, int32_t n, const MetroSpec* spec, int32_t precise,
+                      void* d_partials, float* d_poses_out, void* stream);
+
+const char* metro_last_error(void);
+int32_t metro_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METRO_HIP_H */

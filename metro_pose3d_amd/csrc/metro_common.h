@@ -1,0 +1,91 @@
+// Internal helpers shared by the HIP translation units of libmetro_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/metro_hip.h"
+
+namespace metro {
+
+// thread-local last-error message (metro_last_error)
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define METRO_CHECK_ARG(cond, ...)                  \
+    do {                                            \
+        if (!(cond)) {                              \
+            ::metro::set_error(__VA_ARGS__);        \
+            return METRO_ERR_INVALID_ARG;           \
+        }                                           \
+    } while (0)
+
+#define METRO_HIP_CHECK(expr)                                                              \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            ::metro::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                               __FILE__, __LINE__);                                        \
+            return METRO_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return METRO_ERR_HIP;
+    }
+    return METRO_OK;
+}
+
+// device-side view of MetroConvDesc plus derived values
+struct ConvArgs {
+    int n, h_in, w_in, c_in, in_pix_stride;
+    int h_out, w_out, c_out;
+    int kh, kw, stride, dil, pad_top, pad_left;
+    int res_h, res_w, res_stride, res_offset;
+    int m_total;   // n * h_out * w_out
+    int relu;
+};
+
+inline ConvArgs make_conv_args(const MetroConvDesc& d) {
+    ConvArgs a;
+    a.n = d.n; a.h_in = d.h_in; a.w_in = d.w_in; a.c_in = d.c_in; a.in_pix_stride = d.in_pix_stride;
+    a.h_out = d.h_out; a.w_out = d.w_out; a.c_out = d.c_out;
+    a.kh = d.kh; a.kw = d.kw; a.stride = d.stride; a.dil = d.dilation;
+    a.pad_top = d.pad_top; a.pad_left = d.pad_left;
+    a.res_h = d.res_h; a.res_w = d.res_w; a.res_stride = d.res_stride; a.res_offset = d.res_offset;
+    a.m_total = d.n * d.h_out * d.w_out;
+    a.relu = d.relu;
+    return a;
+}
+
+int validate_conv_desc(const MetroConvDesc* d);
+
+// kernel launchers implemented in the .hip files
+int launch_conv_f16(const MetroConvDesc& d, const void* in, const void* w, const float* bias,
+                    const void* pro_scale, const void* pro_shift, const void* residual, void* out,
+                    hipStream_t stream);
+int launch_conv_f64acc(const MetroConvDesc& d, const float* in, const double* w, const double* bias,
+                       const double* pro_scale, const double* pro_shift, const float* residual,
+                       float* out, hipStream_t stream);
+int launch_prep_input_f16(const float* images, int n, int side, void* out, hipStream_t stream);
+int launch_maxpool(const void* in, void* out, int n, int h_in, int w_in, int c, int dtype,
+                   hipStream_t stream);
+
+struct SoftArgmaxArgs {
+    int n, side, depth, n_joints_head, n_joints_out;
+    int lrc, half_off;           // decode constants (reference volumetric.py:288-295)
+    float box_size_mm;
+    int proc_side;
+    int perm[METRO_MAX_JOINTS];
+};
+int softargmax_slabs(int n, int side);
+int64_t softargmax_scratch_bytes(int n, int side, int n_joints_head);
+int launch_softargmax(const float* logits, const SoftArgmaxArgs& a, bool precise, void* partials,
+                      float* poses_out, hipStream_t stream);
+SoftArgmaxArgs make_softargmax_args(const MetroSpec& spec, int n);
+
+}  // namespace metro

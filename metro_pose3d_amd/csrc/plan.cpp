@@ -1,0 +1,559 @@
+// Planner + executor + C ABI of libmetro_hip.so.
+//
+// metro_plan_create restates, in C++, the graph that the reference builds in Python at export
+// time (reference src/main.py:106-128 -> src/model/volumetric.py:152-216 ->
+// src/model/architectures.py:24-35 -> src/model/resnet_v2.py:142-312 ->
+// src/model/resnet_utils.py:263-350) as a flat list of kernel launches over a pre-planned
+// workspace.  The test-side oracle (oracle/spec.py) restates the same control flow
+// independently in Python; tests/test_plan_vs_oracle.py compares the two layer by layer.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "metro_common.h"
+
+namespace metro {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+int validate_conv_desc(const MetroConvDesc* d) {
+    METRO_CHECK_ARG(d != nullptr, "conv desc is NULL");
+    METRO_CHECK_ARG(d->n > 0 && d->h_in > 0 && d->w_in > 0 && d->c_in > 0 && d->h_out > 0 &&
+                        d->w_out > 0 && d->c_out > 0,
+                    "conv desc: non-positive dimension");
+    METRO_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dilation > 0, "conv desc: bad kernel geometry");
+    METRO_CHECK_ARG(d->in_pix_stride > 0, "conv desc: in_pix_stride must be positive");
+    METRO_CHECK_ARG((long)d->n * d->h_out * d->w_out < (1L << 31), "conv desc: too many output pixels");
+    METRO_CHECK_ARG((long)d->n * d->h_in * d->w_in < (1L << 31), "conv desc: too many input pixels");
+    if (d->has_prologue) {
+        METRO_CHECK_ARG(d->kh == 1 && d->kw == 1, "conv desc: prologue requires a 1x1 kernel");
+        const long last_h = (long)(d->h_out - 1) * d->stride - d->pad_top;
+        const long last_w = (long)(d->w_out - 1) * d->stride - d->pad_left;
+        METRO_CHECK_ARG(d->pad_top <= 0 && d->pad_left <= 0 && last_h < d->h_in && last_w < d->w_in,
+                        "conv desc: prologue requires every tap to be in bounds (no padding)");
+    }
+    if (d->has_residual) {
+        METRO_CHECK_ARG(d->res_stride > 0 && d->res_offset >= 0, "conv desc: bad residual gather");
+        METRO_CHECK_ARG((d->h_out - 1) * d->res_stride + d->res_offset < d->res_h &&
+                            (d->w_out - 1) * d->res_stride + d->res_offset < d->res_w,
+                        "conv desc: residual gather out of bounds");
+    }
+    return METRO_OK;
+}
+
+}  // namespace metro
+
+using namespace metro;
+
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+enum LayerKind { LK_PREP = 0, LK_CONV = 1, LK_POOL = 2, LK_SOFTARGMAX = 3 };
+enum Slot { S_IMAGES = -2, S_NONE = -1, S_PREP = 0, S_STEM, S_X0, S_X1, S_T1, S_T2, S_SC, S_LOGITS, S_PART, S_COUNT };
+
+struct Layer {
+    MetroLayerInfo info;
+    int kind;
+    MetroConvDesc cd;     // cd.n is filled per call
+    int in_slot, out_slot, res_slot;
+    int p_w, p_bias, p_scale, p_shift;
+};
+
+}  // namespace
+
+struct MetroPlan {
+    MetroSpec spec;
+    int max_batch;
+    bool fast;
+    int act_bytes;                       // bytes per activation element in the workspace
+    std::vector<MetroParamInfo> params;
+    std::vector<Layer> layers;
+    int64_t slot_bytes_per_image[S_COUNT];
+    int64_t slot_offset[S_COUNT];
+    int64_t workspace_bytes;
+    int64_t param_bytes;
+    const char* d_params;
+    double flops_per_image;
+};
+
+namespace {
+
+int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct Builder {
+    MetroPlan* p;
+    std::string root;
+
+    int add_param(const std::string& name, int kind, const std::string& conv_var,
+                  const std::string& bn_var, int dtype, int c_out, int kh, int kw, int c_in,
+                  int kw_pad, int c_in_pad) {
+        MetroParamInfo pi;
+        memset(&pi, 0, sizeof(pi));
+        snprintf(pi.name, sizeof(pi.name), "%s", name.c_str());
+        snprintf(pi.conv_var, sizeof(pi.conv_var), "%s", conv_var.c_str());
+        snprintf(pi.bn_var, sizeof(pi.bn_var), "%s", bn_var.c_str());
+        pi.kind = kind; pi.dtype = dtype;
+        pi.c_out = c_out; pi.kh = kh; pi.kw = kw; pi.c_in = c_in; pi.kw_pad = kw_pad; pi.c_in_pad = c_in_pad;
+        const int64_t es = dtype == METRO_F16 ? 2 : dtype == METRO_F32 ? 4 : 8;
+        const int64_t elems = kind == METRO_PARAM_CONV_W ? (int64_t)c_out * kh * kw_pad * c_in_pad : c_out;
+        pi.bytes = elems * es;
+        pi.offset = p->param_bytes;
+        p->param_bytes = align_up(p->param_bytes + pi.bytes, 256);
+        p->params.push_back(pi);
+        return (int)p->params.size() - 1;
+    }
+
+    void need(int slot, int64_t bytes_per_image) {
+        if (slot >= 0) p->slot_bytes_per_image[slot] = std::max(p->slot_bytes_per_image[slot], bytes_per_image);
+    }
+
+    // Adds one convolution.  `scope` is the slim scope below root, e.g.
+    // "block1/unit_1/bottleneck_v2/conv1"; bn_fold = scope of the BN folded into it ("" = the
+    // conv has its own biases); prologue_bn = scope of the pre-activation BN applied to its input.
+    void add_conv(const std::string& lname, const std::string& scope, const std::string& bn_fold,
+                  const std::string& prologue_bn, int in_slot, int out_slot, int res_slot,
+                  int side_in, int c_in, int side_out, int c_out, int k, int stride, int dil,
+                  int pad_beg, bool relu, int res_side, int res_stride, int res_offset,
+                  int out_dtype) {
+        Layer L;
+        memset(&L, 0, sizeof(L));
+        L.kind = LK_CONV;
+        const bool fast = p->fast;
+        const int wdt = fast ? METRO_F16 : METRO_F64;
+        const int bdt = fast ? METRO_F32 : METRO_F64;
+        MetroConvDesc& cd = L.cd;
+        cd.n = 0;
+        cd.h_in = cd.w_in = side_in; cd.c_in = c_in; cd.in_pix_stride = c_in;
+        cd.h_out = cd.w_out = side_out; cd.c_out = c_out;
+        cd.kh = cd.kw = k; cd.stride = stride; cd.dilation = dil;
+        cd.pad_top = cd.pad_left = pad_beg;
+        cd.has_prologue = !prologue_bn.empty();
+        cd.relu = relu;
+        cd.has_residual = res_slot != S_NONE;
+        cd.res_h = cd.res_w = res_side; cd.res_stride = res_stride; cd.res_offset = res_offset;
+        cd.out_dtype = out_dtype;
+        const std::string conv_var = root + "/" + scope;
+        const std::string bn_var = bn_fold.empty() ? "" : root + "/" + bn_fold;
+        L.p_w = add_param(lname + "/W", METRO_PARAM_CONV_W, conv_var, bn_var, wdt, c_out, k, k, c_in, k, c_in);
+        L.p_bias = add_param(lname + "/bias", METRO_PARAM_BIAS, conv_var, bn_var, bdt, c_out, 1, 1, 1, 1, 1);
+        L.p_scale = L.p_shift = -1;
+        if (cd.has_prologue) {
+            const std::string pv = root + "/" + prologue_bn;
+            L.p_scale = add_param(lname + "/pro_scale", METRO_PARAM_PRO_SCALE, "", pv, wdt, c_in, 1, 1, 1, 1, 1);
+            L.p_shift = add_param(lname + "/pro_shift", METRO_PARAM_PRO_SHIFT, "", pv, wdt, c_in, 1, 1, 1, 1, 1);
+        }
+        L.in_slot = in_slot; L.out_slot = out_slot; L.res_slot = res_slot;
+        const int64_t out_es = out_dtype == METRO_F16 ? 2 : 4;
+        need(out_slot, (int64_t)side_out * side_out * c_out * out_es);
+        fill_info(L, lname, (double)2.0 * side_out * side_out * c_out * k * k * c_in);
+        p->layers.push_back(L);
+    }
+
+    void fill_info(Layer& L, const std::string& lname, double flops) {
+        MetroLayerInfo& I = L.info;
+        snprintf(I.name, sizeof(I.name), "%s", lname.c_str());
+        I.kind = L.kind;
+        const MetroConvDesc& cd = L.cd;
+        I.h_in = cd.h_in; I.w_in = cd.w_in; I.c_in = cd.c_in; I.h_out = cd.h_out; I.w_out = cd.w_out;
+        I.c_out = cd.c_out; I.kh = cd.kh; I.kw = cd.kw; I.stride = cd.stride; I.dilation = cd.dilation;
+        I.pad_top = cd.pad_top; I.pad_left = cd.pad_left;
+        I.has_prologue = cd.has_prologue; I.relu = cd.relu; I.has_residual = cd.has_residual;
+        I.res_stride = cd.res_stride; I.res_offset = cd.res_offset;
+        I.out_dtype = cd.out_dtype;
+        I.flops_per_image = flops;
+        p->flops_per_image += flops;
+    }
+};
+
+// TF 'SAME' padding: out = ceil(in/s); total = max((out-1)*s + k_eff - in, 0); beg = total/2
+int tf_same_pad_beg(int in, int k_eff, int s) {
+    const int out = (in + s - 1) / s;
+    const int total = std::max((out - 1) * s + k_eff - in, 0);
+    return total / 2;
+}
+
+int build_plan(MetroPlan* p) {
+    const MetroSpec& sp = p->spec;
+    Builder B{p, std::string("MainPart/resnet_v2_") + std::to_string(sp.arch)};
+    const bool fast = p->fast;
+    const int adt = fast ? METRO_F16 : METRO_F32;
+    const int aes = p->act_bytes;
+    const int side = sp.proc_side;
+    const int bw = sp.base_width;
+
+    // ---- root block: conv1 7x7/2 with explicit pad 3 (+bias, no BN, no ReLU), pool1 ----------
+    // reference resnet_v2.py:219-224, resnet_utils.py:125-135,177-185
+    const int s2 = (side + 6 - 7) / 2 + 1;   // 128
+    if (fast) {
+        Layer L;
+        memset(&L, 0, sizeof(L));
+        L.kind = LK_PREP;
+        L.cd.h_in = L.cd.w_in = side; L.cd.c_in = 3;
+        L.cd.h_out = side + 6; L.cd.w_out = side + 8; L.cd.c_out = 4; L.cd.out_dtype = METRO_F16;
+        L.in_slot = S_IMAGES; L.out_slot = S_PREP; L.res_slot = S_NONE;
+        L.p_w = L.p_bias = L.p_scale = L.p_shift = -1;
+        B.need(S_PREP, (int64_t)(side + 6) * (side + 8) * 4 * 2);
+        B.fill_info(L, "prep_input", 0.0);
+        p->layers.push_back(L);
+
+        // stem as a pad-free 7x1-tap conv over the bordered 4-channel image: each tap = 8
+        // pixels x 4 channels = 32 contiguous fp16; weights packed [c_out][7][8][4] (zeros in
+        // the 8th pixel and the 4th channel).
+        Layer S;
+        memset(&S, 0, sizeof(S));
+        S.kind = LK_CONV;
+        MetroConvDesc& cd = S.cd;
+        cd.h_in = side + 6; cd.w_in = side + 8; cd.c_in = 32; cd.in_pix_stride = 4;
+        cd.h_out = cd.w_out = s2; cd.c_out = bw;
+        cd.kh = 7; cd.kw = 1; cd.stride = 2; cd.dilation = 1; cd.pad_top = cd.pad_left = 0;
+        cd.out_dtype = adt;
+        const std::string cv = B.root + "/conv1";
+        S.p_w = B.add_param("conv1/W", METRO_PARAM_CONV_W, cv, "", METRO_F16, bw, 7, 7, 3, 8, 4);
+        S.p_bias = B.add_param("conv1/bias", METRO_PARAM_BIAS, cv, "", METRO_F32, bw, 1, 1, 1, 1, 1);
+        S.p_scale = S.p_shift = -1;
+        S.in_slot = S_PREP; S.out_slot = S_STEM; S.res_slot = S_NONE;
+        B.need(S_STEM, (int64_t)s2 * s2 * bw * aes);
+        B.fill_info(S, "conv1", 2.0 * s2 * s2 * bw * 7 * 7 * 3);
+        p->layers.push_back(S);
+    } else {
+        B.add_conv("conv1", "conv1", "", "", S_IMAGES, S_STEM, S_NONE, side, 3, s2, bw, 7, 2, 1, 3,
+                   false, 0, 1, 0, adt);
+    }
+    const int s4 = (s2 + 2 - 3) / 2 + 1;     // 64
+    {
+        Layer L;
+        memset(&L, 0, sizeof(L));
+        L.kind = LK_POOL;
+        L.cd.h_in = L.cd.w_in = s2; L.cd.c_in = bw; L.cd.h_out = L.cd.w_out = s4; L.cd.c_out = bw;
+        L.cd.kh = L.cd.kw = 3; L.cd.stride = 2; L.cd.dilation = 1; L.cd.pad_top = L.cd.pad_left = 1;
+        L.cd.out_dtype = adt;
+        L.in_slot = S_STEM; L.out_slot = S_X0; L.res_slot = S_NONE;
+        L.p_w = L.p_bias = L.p_scale = L.p_shift = -1;
+        B.need(S_X0, (int64_t)s4 * s4 * bw * aes);
+        B.fill_info(L, "pool1", 0.0);
+        p->layers.push_back(L);
+    }
+
+    // ---- block table (reference resnet_v2.py:272-312) ---------------------------------------
+    bool centered[3] = {false, false, false};
+    if (sp.centered_stride) {
+        if (sp.arch == 50) {
+            const int i_last = (int)std::lround(std::log2((double)sp.stride)) - 3;   // :279-281
+            if (i_last >= 0 && i_last < 3) centered[i_last] = true;
+        } else {
+            int i_last = (int)std::log2((double)sp.stride) - 3;                      // :301-302
+            if (i_last < 0) i_last += 3;   // Python c[-1]
+            if (i_last >= 0 && i_last < 3) centered[i_last] = true;
+        }
+    }
+    const int n_units[4] = {3, 4, sp.arch == 50 ? 6 : 23, 3};
+    const int base[4] = {bw, 2 * bw, 4 * bw, 8 * bw};
+    const int block_stride[4] = {2, 2, 2, 1};
+
+    // ---- stack_blocks_dense (reference resnet_utils.py:307-348) ------------------------------
+    const double output_stride = sp.stride / 4.0;    // resnet_v2.py:215 (float division)
+    int current_stride = 1, rate = 1;
+    int cur_side = s4, cur_c = bw, cur = S_X0;
+    for (int b = 0; b < 4; ++b) {
+        for (int u = 1; u <= n_units[b]; ++u) {
+            const int unit_stride = u == n_units[b] ? block_stride[b] : 1;   // resnet_v2.py:260-269
+            const bool unit_centered = u == n_units[b] && b < 3 && centered[b];
+            int s, r;
+            if ((double)current_stride == output_stride) {
+                s = 1; r = rate; rate *= unit_stride;                        // :325-327
+            } else {
+                s = unit_stride; r = 1; current_stride *= unit_stride;       // :329-333
+                if ((double)current_stride > output_stride) { set_error("The target output_stride cannot be reached."); return METRO_ERR_INVALID_ARG; }
+            }
+            const int cb = base[b], cout = 4 * base[b];
+            const int side_out = s == 2 ? (cur_side + 1) / 2 : cur_side;
+            const std::string un = "block" + std::to_string(b + 1) + "/unit_" + std::to_string(u);
+            const std::string sc = un + "/bottleneck_v2";
+            const int shift = (unit_centered && s == 2) ? 1 : 0;             // resnet_v2.py:113-115
+            const int nxt = cur == S_X0 ? S_X1 : S_X0;
+            const bool project = cur_c != cout;                              // resnet_v2.py:120-125
+            if (project) {
+                // conv1x1(shift(preact), stride s) + bias: input pixel = shift + s*ho
+                B.add_conv(un + "/shortcut", sc + "/shortcut", "", sc + "/preact", cur, S_SC, S_NONE,
+                           cur_side, cur_c, side_out, cout, 1, s, 1, -shift, false, 0, 1, 0, adt);
+            }
+            // conv1: 1x1 on preact, BN+ReLU folded (resnet_v2.py:127-128)
+            B.add_conv(un + "/conv1", sc + "/conv1", sc + "/conv1/BatchNorm", sc + "/preact", cur, S_T1,
+                       S_NONE, cur_side, cur_c, cur_side, cb, 1, 1, 1, 0, true, 0, 1, 0, adt);
+            // conv2: conv2d_same 3x3 (resnet_utils.py:82-135)
+            const int k_eff = 3 + 2 * (r - 1);
+            const int pad_beg = (s == 1 || unit_centered) ? tf_same_pad_beg(cur_side, k_eff, s)
+                                                          : (k_eff - 1) / 2;
+            B.add_conv(un + "/conv2", sc + "/conv2", sc + "/conv2/BatchNorm", "", S_T1, S_T2, S_NONE,
+                       cur_side, cb, side_out, cb, 3, s, r, pad_beg, true, 0, 1, 0, adt);
+            // conv3 + bias + shortcut (resnet_v2.py:134-138)
+            if (project)
+                B.add_conv(un + "/conv3", sc + "/conv3", "", "", S_T2, nxt, S_SC, side_out, cb, side_out,
+                           cout, 1, 1, 1, 0, false, side_out, 1, 0, adt);
+            else
+                B.add_conv(un + "/conv3", sc + "/conv3", "", "", S_T2, nxt, cur, side_out, cb, side_out,
+                           cout, 1, 1, 1, 0, false, cur_side, s, shift, adt);
+            cur = nxt; cur_side = side_out; cur_c = cout;
+        }
+    }
+    if ((double)current_stride != output_stride) { set_error("The target output_stride cannot be reached."); return METRO_ERR_INVALID_ARG; }
+    if (cur_side != sp.proc_side / sp.stride) { set_error("internal: output side %d != %d", cur_side, sp.proc_side / sp.stride); return METRO_ERR_STATE; }
+
+    // ---- postnorm (prologue) + logits 1x1 (+bias), fp32 out (resnet_v2.py:229-236, architectures.py:34)
+    const int c_head = sp.depth * sp.n_joints_head;
+    B.add_conv("logits", "logits", "", "postnorm", cur, S_LOGITS, S_NONE, cur_side, cur_c, cur_side,
+               c_head, 1, 1, 1, 0, false, 0, 1, 0, METRO_F32);
+
+    // ---- soft-argmax + decode ---------------------------------------------------------------
+    {
+        Layer L;
+        memset(&L, 0, sizeof(L));
+        L.kind = LK_SOFTARGMAX;
+        L.cd.h_in = L.cd.w_in = cur_side; L.cd.c_in = c_head; L.cd.h_out = 1; L.cd.w_out = sp.n_joints_out;
+        L.cd.c_out = 3; L.cd.out_dtype = METRO_F32;
+        L.in_slot = S_LOGITS; L.out_slot = S_NONE; L.res_slot = S_NONE;
+        L.p_w = L.p_bias = L.p_scale = L.p_shift = -1;
+        B.fill_info(L, "softargmax", 0.0);
+        p->layers.push_back(L);
+    }
+
+    // ---- workspace layout ------------------------------------------------------------------
+    int64_t off = 0;
+    for (int s = 0; s < S_COUNT; ++s) {
+        p->slot_offset[s] = off;
+        int64_t bytes = p->slot_bytes_per_image[s] * p->max_batch;
+        if (s == S_PART) bytes = (int64_t)(512 + p->max_batch) * sp.n_joints_head * 5 * sizeof(double);
+        off = align_up(off + bytes, 256);
+    }
+    p->workspace_bytes = off;
+    for (Layer& L : p->layers) {
+        L.info.out_offset = L.out_slot >= 0 ? p->slot_offset[L.out_slot] : -1;
+        const int64_t es = L.cd.out_dtype == METRO_F16 ? 2 : 4;
+        L.info.out_bytes_per_image = (int64_t)L.cd.h_out * L.cd.w_out * L.cd.c_out * es;
+    }
+    return METRO_OK;
+}
+
+int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_, hipStream_t stream,
+               int last_layer, float* ms_out) {
+    METRO_CHECK_ARG(p != nullptr, "plan is NULL");
+    METRO_CHECK_ARG(n > 0 && n <= p->max_batch, "batch %d outside [1, %d]", n, p->max_batch);
+    METRO_CHECK_ARG(images != nullptr && ws_ != nullptr, "NULL images/workspace pointer");
+    if (p->d_params == nullptr) { set_error("metro_forward: parameters not bound (metro_plan_bind_params)"); return METRO_ERR_STATE; }
+    char* ws = static_cast<char*>(ws_);
+    const int nl = (int)p->layers.size();
+    if (last_layer < 0 || last_layer >= nl) last_layer = nl - 1;
+
+    std::vector<hipEvent_t> ev;
+    if (ms_out) {
+        ev.resize(2 * (last_layer + 1));
+        for (auto& e : ev) METRO_HIP_CHECK(hipEventCreate(&e));
+    }
+    auto slot_ptr = [&](int slot) -> void* {
+        if (slot == S_IMAGES) return const_cast<float*>(images);
+        if (slot < 0) return nullptr;
+        return ws + p->slot_offset[slot];
+    };
+    auto prm = [&](int idx) -> const void* { return idx < 0 ? nullptr : p->d_params + p->params[idx].offset; };
+
+    int st = METRO_OK;
+    for (int li = 0; li <= last_layer && st == METRO_OK; ++li) {
+        Layer& L = p->layers[li];
+        if (ms_out) METRO_HIP_CHECK(hipEventRecord(ev[2 * li], stream));
+        switch (L.kind) {
+            case LK_PREP:
+                st = launch_prep_input_f16(images, n, p->spec.proc_side, slot_ptr(L.out_slot), stream);
+                break;
+            case LK_POOL:
+                st = launch_maxpool(slot_ptr(L.in_slot), slot_ptr(L.out_slot), n, L.cd.h_in, L.cd.w_in,
+                                    L.cd.c_in, p->fast ? METRO_F16 : METRO_F32, stream);
+                break;
+            case LK_CONV: {
+                MetroConvDesc cd = L.cd;
+                cd.n = n;
+                if (p->fast)
+                    st = launch_conv_f16(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
+                                         prm(L.p_scale), prm(L.p_shift), slot_ptr(L.res_slot),
+                                         slot_ptr(L.out_slot), stream);
+                else
+                    st = launch_conv_f64acc(cd, static_cast<const float*>(slot_ptr(L.in_slot)),
+                                            static_cast<const double*>(prm(L.p_w)),
+                                            static_cast<const double*>(prm(L.p_bias)),
+                                            static_cast<const double*>(prm(L.p_scale)),
+                                            static_cast<const double*>(prm(L.p_shift)),
+                                            static_cast<const float*>(slot_ptr(L.res_slot)),
+                                            static_cast<float*>(slot_ptr(L.out_slot)), stream);
+                break;
+            }
+            case LK_SOFTARGMAX: {
+                if (poses == nullptr) { set_error("metro_forward: poses_out is NULL"); st = METRO_ERR_INVALID_ARG; break; }
+                const SoftArgmaxArgs a = make_softargmax_args(p->spec, n);
+                st = launch_softargmax(static_cast<const float*>(slot_ptr(L.in_slot)), a, !p->fast,
+                                       slot_ptr(S_PART), poses, stream);
+                break;
+            }
+        }
+        if (ms_out) METRO_HIP_CHECK(hipEventRecord(ev[2 * li + 1], stream));
+    }
+    if (ms_out) {
+        if (st == METRO_OK) {
+            METRO_HIP_CHECK(hipEventSynchronize(ev.back()));
+            for (int li = 0; li <= last_layer; ++li) {
+                float ms = 0.f;
+                METRO_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * li], ev[2 * li + 1]));
+                ms_out[li] += ms;
+            }
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    return st;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int metro_plan_create(const MetroSpec* spec, int32_t max_batch, MetroPlan** out_plan) {
+    METRO_CHECK_ARG(spec != nullptr && out_plan != nullptr, "metro_plan_create: NULL argument");
+    *out_plan = nullptr;
+    METRO_CHECK_ARG(spec->arch == 50 || spec->arch == 101, "unsupported arch %d (50|101)", spec->arch);
+    METRO_CHECK_ARG(spec->stride == 4 || spec->stride == 8 || spec->stride == 16 || spec->stride == 32,
+                    "unsupported stride %d (4|8|16|32)", spec->stride);
+    METRO_CHECK_ARG(spec->proc_side > 0 && spec->proc_side % 32 == 0, "proc_side %d must be a positive multiple of 32", spec->proc_side);
+    METRO_CHECK_ARG(spec->depth >= 2 && spec->depth <= 64, "depth %d out of range", spec->depth);
+    METRO_CHECK_ARG(spec->n_joints_head >= 1 && spec->n_joints_head <= METRO_MAX_JOINTS, "n_joints_head %d out of range", spec->n_joints_head);
+    METRO_CHECK_ARG(spec->n_joints_out >= 1 && spec->n_joints_out <= METRO_MAX_JOINTS, "n_joints_out %d out of range", spec->n_joints_out);
+    for (int i = 0; i < spec->n_joints_out; ++i)
+        METRO_CHECK_ARG(spec->permutation[i] >= 0 && spec->permutation[i] < spec->n_joints_head,
+                        "permutation[%d] = %d outside the head's %d joints", i, spec->permutation[i], spec->n_joints_head);
+    METRO_CHECK_ARG((spec->depth * spec->n_joints_head) % 4 == 0, "depth*n_joints_head must be a multiple of 4");
+    METRO_CHECK_ARG(spec->precision == METRO_PREC_F16 || spec->precision == METRO_PREC_F32, "unknown precision %d", spec->precision);
+    METRO_CHECK_ARG(spec->base_width >= 8 && spec->base_width % 8 == 0, "base_width %d must be a positive multiple of 8", spec->base_width);
+    METRO_CHECK_ARG(max_batch >= 1 && max_batch <= 4096, "max_batch %d out of range", max_batch);
+    METRO_CHECK_ARG(spec->box_size_mm > 0.f, "box_size_mm must be positive");
+
+    MetroPlan* p = new MetroPlan();
+    p->spec = *spec;
+    p->max_batch = max_batch;
+    p->fast = spec->precision == METRO_PREC_F16;
+    p->act_bytes = p->fast ? 2 : 4;
+    for (int s = 0; s < S_COUNT; ++s) { p->slot_bytes_per_image[s] = 0; p->slot_offset[s] = 0; }
+    p->workspace_bytes = 0; p->param_bytes = 0; p->d_params = nullptr; p->flops_per_image = 0.0;
+    const int st = build_plan(p);
+    if (st != METRO_OK) { delete p; return st; }
+    *out_plan = p;
+    return METRO_OK;
+}
+
+int metro_plan_destroy(MetroPlan* plan) { delete plan; return METRO_OK; }
+int64_t metro_plan_workspace_bytes(const MetroPlan* plan) { return plan ? plan->workspace_bytes : -1; }
+int64_t metro_plan_param_bytes(const MetroPlan* plan) { return plan ? plan->param_bytes : -1; }
+int32_t metro_plan_num_params(const MetroPlan* plan) { return plan ? (int32_t)plan->params.size() : -1; }
+int32_t metro_plan_num_layers(const MetroPlan* plan) { return plan ? (int32_t)plan->layers.size() : -1; }
+double metro_plan_flops_per_image(const MetroPlan* plan) { return plan ? plan->flops_per_image : -1.0; }
+
+int metro_plan_param_info(const MetroPlan* plan, int32_t index, MetroParamInfo* out) {
+    METRO_CHECK_ARG(plan && out && index >= 0 && index < (int)plan->params.size(), "metro_plan_param_info: bad argument");
+    *out = plan->params[index];
+    return METRO_OK;
+}
+
+int metro_plan_layer_info(const MetroPlan* plan, int32_t index, MetroLayerInfo* out) {
+    METRO_CHECK_ARG(plan && out && index >= 0 && index < (int)plan->layers.size(), "metro_plan_layer_info: bad argument");
+    *out = plan->layers[index].info;
+    return METRO_OK;
+}
+
+int metro_plan_bind_params(MetroPlan* plan, const void* d_param_blob) {
+    METRO_CHECK_ARG(plan && d_param_blob, "metro_plan_bind_params: NULL argument");
+    METRO_CHECK_ARG(((uintptr_t)d_param_blob & 255) == 0, "parameter blob must be 256-byte aligned");
+    plan->d_params = static_cast<const char*>(d_param_blob);
+    return METRO_OK;
+}
+
+int metro_forward(MetroPlan* plan, const float* d_images_nhwc, int32_t n, float* d_poses_out,
+                  void* d_workspace, void* stream) {
+    return run_layers(plan, d_images_nhwc, n, d_poses_out, d_workspace, static_cast<hipStream_t>(stream), -1, nullptr);
+}
+
+int metro_forward_upto(MetroPlan* plan, const float* d_images_nhwc, int32_t n, float* d_poses_out,
+                       void* d_workspace, void* stream, int32_t last_layer) {
+    return run_layers(plan, d_images_nhwc, n, d_poses_out, d_workspace, static_cast<hipStream_t>(stream), last_layer, nullptr);
+}
+
+int metro_forward_timed(MetroPlan* plan, const float* d_images_nhwc, int32_t n, float* d_poses_out,
+                        void* d_workspace, void* stream, float* ms_out) {
+    METRO_CHECK_ARG(ms_out != nullptr, "metro_forward_timed: ms_out is NULL");
+    return run_layers(plan, d_images_nhwc, n, d_poses_out, d_workspace, static_cast<hipStream_t>(stream), -1, ms_out);
+}
+
+int metro_conv_f16(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
+                   const void* d_pro_scale, const void* d_pro_shift, const void* d_residual,
+                   void* d_out, void* stream) {
+    int st = validate_conv_desc(d);
+    if (st) return st;
+    METRO_CHECK_ARG(d->c_in % 8 == 0 && d->in_pix_stride % 4 == 0, "conv_f16: c_in must be a multiple of 8 (got %d) and in_pix_stride of 4", d->c_in);
+    METRO_CHECK_ARG(d->c_out % 4 == 0, "conv_f16: c_out must be a multiple of 4 (got %d)", d->c_out);
+    METRO_CHECK_ARG(d->out_dtype == METRO_F16 || d->out_dtype == METRO_F32, "conv_f16: out_dtype must be F16 or F32");
+    METRO_CHECK_ARG(d_in && d_w && d_bias && d_out, "conv_f16: NULL tensor pointer");
+    METRO_CHECK_ARG(!d->has_prologue || (d_pro_scale && d_pro_shift), "conv_f16: prologue tensors missing");
+    METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f16: residual tensor missing");
+    return launch_conv_f16(*d, d_in, d_w, d_bias, d_pro_scale, d_pro_shift, d_residual, d_out,
+                           static_cast<hipStream_t>(stream));
+}
+
+int metro_conv_f64acc(const MetroConvDesc* d, const float* d_in, const double* d_w, const double* d_bias,
+                      const double* d_pro_scale, const double* d_pro_shift, const float* d_residual,
+                      float* d_out, void* stream) {
+    int st = validate_conv_desc(d);
+    if (st) return st;
+    METRO_CHECK_ARG(d->out_dtype == METRO_F32, "conv_f64acc: out_dtype must be F32");
+    METRO_CHECK_ARG(d_in && d_w && d_bias && d_out, "conv_f64acc: NULL tensor pointer");
+    METRO_CHECK_ARG(!d->has_prologue || (d_pro_scale && d_pro_shift), "conv_f64acc: prologue tensors missing");
+    METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f64acc: residual tensor missing");
+    return launch_conv_f64acc(*d, d_in, d_w, d_bias, d_pro_scale, d_pro_shift, d_residual, d_out,
+                              static_cast<hipStream_t>(stream));
+}
+
+int metro_prep_input_f16(const float* d_images, int32_t n, int32_t side, void* d_out, void* stream) {
+    METRO_CHECK_ARG(d_images && d_out && n > 0 && side > 0, "prep_input_f16: bad argument");
+    return launch_prep_input_f16(d_images, n, side, d_out, static_cast<hipStream_t>(stream));
+}
+
+int metro_maxpool3x3s2_zeropad(const void* d_in, void* d_out, int32_t n, int32_t h_in, int32_t w_in,
+                               int32_t c, int32_t dtype, void* stream) {
+    METRO_CHECK_ARG(d_in && d_out && n > 0 && h_in > 0 && w_in > 0 && c > 0, "maxpool: bad argument");
+    return launch_maxpool(d_in, d_out, n, h_in, w_in, c, dtype, static_cast<hipStream_t>(stream));
+}
+
+int64_t metro_softargmax_scratch_bytes(int32_t n, int32_t side, int32_t n_joints_head) {
+    if (n <= 0 || side <= 1 || n_joints_head <= 0) return -1;
+    return softargmax_scratch_bytes(n, side, n_joints_head);
+}
+
+int metro_softargmax(const float* d_logits, int32_t n, const MetroSpec* spec, int32_t precise,
+                     void* d_partials, float* d_poses_out, void* stream) {
+    METRO_CHECK_ARG(d_logits && spec && d_partials && d_poses_out && n > 0, "softargmax: bad argument");
+    METRO_CHECK_ARG(spec->n_joints_head >= 1 && spec->n_joints_head <= METRO_MAX_JOINTS &&
+                        spec->n_joints_out >= 1 && spec->n_joints_out <= METRO_MAX_JOINTS,
+                    "softargmax: joint counts out of range");
+    METRO_CHECK_ARG(spec->proc_side / spec->stride >= 2, "softargmax: heat-map side must be >= 2");
+    const SoftArgmaxArgs a = make_softargmax_args(*spec, n);
+    return launch_softargmax(d_logits, a, precise != 0, d_partials, d_poses_out, static_cast<hipStream_t>(stream));
+}
+
+const char* metro_last_error(void) { return metro::get_error(); }
+int32_t metro_abi_version(void) { return METRO_ABI_VERSION; }
+
+}  // extern "C"

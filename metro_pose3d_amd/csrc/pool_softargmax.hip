@@ -1,0 +1,326 @@
+// HBM-bound kernels of the path: input preparation, zero-padded max-pool, and the
+// softmax-over-volume + expectation soft-argmax with mm decode.
+#include "metro_common.h"
+
+namespace metro {
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// fp32 NHWC [n,side,side,3] -> fp16 [n,side+6,side+8,4], zero border (3 top/left, 3/5
+// bottom/right) and zero 4th channel.  Materialises the stem's explicit pad-3 (reference
+// resnet_utils.py:125-135) and the fp32->fp16 cast (architectures.py:29) once, so the 7x7/2
+// stem becomes a pad-free 7x1-tap implicit GEMM whose taps are 8 pixels x 4 channels = 32
+// contiguous fp16 (the 8th pixel meets zero weights).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_input_f16_kernel(const float* __restrict__ img,
+                                                             half4_t* __restrict__ out, int n,
+                                                             int side) {
+    const int hp = side + 6, wp = side + 8;
+    const long total = (long)n * hp * wp;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+         p += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(p % wp);
+        const long t = p / wp;
+        const int y = (int)(t % hp);
+        const int im = (int)(t / hp);
+        half4_t v = {(half_t)0, (half_t)0, (half_t)0, (half_t)0};
+        const int yi = y - 3, xi = x - 3;
+        if ((unsigned)yi < (unsigned)side && (unsigned)xi < (unsigned)side) {
+            const float* s = img + ((size_t)(im * side + yi) * side + xi) * 3;
+            v[0] = (half_t)s[0]; v[1] = (half_t)s[1]; v[2] = (half_t)s[2];
+        }
+        out[p] = v;
+    }
+}
+
+int launch_prep_input_f16(const float* images, int n, int side, void* out, hipStream_t stream) {
+    const long total = (long)n * (side + 6) * (side + 8);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(prep_input_f16_kernel, dim3(blocks), dim3(256), 0, stream, images,
+                       static_cast<half4_t*>(out), n, side);
+    return launch_status("prep_input_f16");
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 stride-2 max-pool over an input ZERO-padded by (1,1) (reference resnet_utils.py:177-185:
+// array_ops.pad then VALID pooling -> the pad value 0 takes part in the max).
+// One thread per (output pixel, 16-byte channel chunk).
+// ---------------------------------------------------------------------------------------------
+template <typename VecT, int VEC>
+__global__ __launch_bounds__(256) void maxpool3x3s2_zeropad_kernel(const VecT* __restrict__ in,
+                                                                   VecT* __restrict__ out, int n,
+                                                                   int h_in, int w_in, int cvec) {
+    const int h_out = (h_in + 2 - 3) / 2 + 1, w_out = (w_in + 2 - 3) / 2 + 1;
+    const long total = (long)n * h_out * w_out * cvec;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % cvec);
+        long t = idx / cvec;
+        const int wo = (int)(t % w_out);
+        t /= w_out;
+        const int ho = (int)(t % h_out);
+        const int im = (int)(t / h_out);
+        VecT best;
+        bool first = true;
+        bool touched_pad = false;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = 2 * ho - 1 + r;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = 2 * wo - 1 + s;
+                if ((unsigned)hi < (unsigned)h_in && (unsigned)wi < (unsigned)w_in) {
+                    const VecT v = in[((size_t)(im * h_in + hi) * w_in + wi) * cvec + cv];
+                    if (first) { best = v; first = false; }
+                    else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) best[e] = v[e] > best[e] ? v[e] : best[e];
+                    }
+                } else {
+                    touched_pad = true;
+                }
+            }
+        }
+        if (touched_pad) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) best[e] = best[e] > 0 ? best[e] : 0;
+        }
+        out[idx] = best;
+    }
+}
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+int launch_maxpool(const void* in, void* out, int n, int h_in, int w_in, int c, int dtype,
+                   hipStream_t stream) {
+    const int h_out = (h_in + 2 - 3) / 2 + 1, w_out = (w_in + 2 - 3) / 2 + 1;
+    if (dtype == METRO_F16) {
+        if (c % 8) { set_error("maxpool f16: channels %d not a multiple of 8", c); return METRO_ERR_INVALID_ARG; }
+        const long total = (long)n * h_out * w_out * (c / 8);
+        const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL((maxpool3x3s2_zeropad_kernel<half8_t, 8>), dim3(blocks), dim3(256), 0, stream,
+                           static_cast<const half8_t*>(in), static_cast<half8_t*>(out), n, h_in, w_in, c / 8);
+    } else if (dtype == METRO_F32) {
+        if (c % 4) { set_error("maxpool f32: channels %d not a multiple of 4", c); return METRO_ERR_INVALID_ARG; }
+        const long total = (long)n * h_out * w_out * (c / 4);
+        const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL((maxpool3x3s2_zeropad_kernel<floatx4, 4>), dim3(blocks), dim3(256), 0, stream,
+                           static_cast<const floatx4*>(in), static_cast<floatx4*>(out), n, h_in, w_in, c / 4);
+    } else {
+        set_error("maxpool: unsupported dtype %d", dtype);
+        return METRO_ERR_INVALID_ARG;
+    }
+    return launch_status("maxpool3x3s2_zeropad");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Soft-argmax.  logits fp32 NHWC [n, S, S, C = D*J], channel c = d*J + j (reference
+// volumetric.py:230-232).  Per (image, joint): softmax over all S*S*D voxels (tfu.py:466-471),
+// then expectation of linspace(0,1,.) coordinates along W (x), H (y), D (z) (tfu.py:474-499 with
+// axes [3,2,4], volumetric.py:234).
+//
+// Kernel 1 (partials): grid (slabs, n).  A slab is a contiguous range of pixels; since NHWC
+// keeps a pixel's C channels contiguous, the slab is one contiguous float range read with
+// 16-byte loads.  Thread (pp, q) owns the channel quad q (4 consecutive channels) and walks
+// pixels pp, pp+PPB, ... keeping an ONLINE softmax state (running max m, sum e, sum e*x,
+// sum e*y) per channel: logits are read exactly once.  The block then folds the PPB pixel
+// lanes and the D depth channels of each joint through LDS and emits
+// (m, S, Sx, Sy, Sz) per (image, slab, joint).
+// Kernel 2 (finalize): folds the slabs, divides, decodes to millimetres
+// (volumetric.py:288-295,303-306), subtracts the root = last head joint (tfu3d.py:23-25) and
+// gathers the exported joint order (main.py:119-127).
+// ---------------------------------------------------------------------------------------------
+constexpr int SA_NT = 256;
+
+int softargmax_slabs(int n, int side) {
+    // enough blocks to cover 256 CUs about twice, but no slab smaller than 8 pixels
+    const int pixels = side * side;
+    int slabs = (512 + n - 1) / n;
+    if (slabs > pixels / 8) slabs = pixels / 8;
+    if (slabs < 1) slabs = 1;
+    return slabs;
+}
+
+int64_t softargmax_scratch_bytes(int n, int side, int n_joints_head) {
+    return (int64_t)n * softargmax_slabs(n, side) * n_joints_head * 5 * sizeof(double);
+}
+
+template <typename AccT>
+__device__ __forceinline__ AccT acc_exp(AccT x);
+template <> __device__ __forceinline__ float acc_exp<float>(float x) { return __expf(x); }
+template <> __device__ __forceinline__ double acc_exp<double>(double x) { return exp(x); }
+
+template <typename AccT>
+__global__ __launch_bounds__(SA_NT) void softargmax_partial_kernel(
+    const float* __restrict__ logits, AccT* __restrict__ partials, int side, int depth, int nj,
+    int slabs) {
+    extern __shared__ __attribute__((aligned(16))) char sa_smem[];
+    AccT* red = reinterpret_cast<AccT*>(sa_smem);   // [ppb][C][4]: m, s, sx, sy
+
+    const int C = depth * nj;
+    const int quads = C / 4;
+    const int ppb = SA_NT / quads;            // pixel lanes per block
+    const int tid = threadIdx.x;
+    const int pp = tid / quads;
+    const int q = tid - pp * quads;
+    const int img = blockIdx.y;
+    const int slab = blockIdx.x;
+    const int pixels = side * side;
+    const int p_begin = (int)((long)pixels * slab / slabs);
+    const int p_end = (int)((long)pixels * (slab + 1) / slabs);
+    const float step_s = 1.0f / (float)(side - 1);   // tf.linspace step in fp32 (tfu.py:481)
+
+    AccT m[4], s[4], sx[4], sy[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m[e] = (AccT)-INFINITY; s[e] = 0; sx[e] = 0; sy[e] = 0; }
+
+    if (pp < ppb) {
+        const float* base = logits + (size_t)img * pixels * C + q * 4;
+        for (int p = p_begin + pp; p < p_end; p += ppb) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * C);
+            const int h = p / side;
+            const int wq = p - h * side;
+            const AccT cx = (AccT)((float)wq * step_s);
+            const AccT cy = (AccT)((float)h * step_s);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const AccT x = (AccT)vv[e];
+                if (x > m[e]) {                      // rare after the first few pixels
+                    const AccT f = acc_exp<AccT>(m[e] - x);   // exp(-inf) = 0 on first touch
+                    s[e] *= f; sx[e] *= f; sy[e] *= f;
+                    m[e] = x;
+                }
+                const AccT ex = acc_exp<AccT>(x - m[e]);
+                s[e] += ex; sx[e] += ex * cx; sy[e] += ex * cy;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            AccT* r = red + ((size_t)pp * C + q * 4 + e) * 4;
+            r[0] = m[e]; r[1] = s[e]; r[2] = sx[e]; r[3] = sy[e];
+        }
+    }
+    __syncthreads();
+
+    // fold: one thread per joint
+    if (tid < nj) {
+        const int j = tid;
+        const float step_d = 1.0f / (float)(depth - 1);
+        AccT M = (AccT)-INFINITY;
+        for (int l = 0; l < ppb; ++l)
+            for (int d = 0; d < depth; ++d) {
+                const AccT mv = red[((size_t)l * C + d * nj + j) * 4];
+                M = mv > M ? mv : M;
+            }
+        AccT S = 0, SX = 0, SY = 0, SZ = 0;
+        for (int l = 0; l < ppb; ++l)
+            for (int d = 0; d < depth; ++d) {
+                const AccT* r = red + ((size_t)l * C + d * nj + j) * 4;
+                if (r[1] > 0) {
+                    const AccT f = acc_exp<AccT>(r[0] - M);
+                    const AccT cz = (AccT)((float)d * step_d);
+                    S += r[1] * f; SX += r[2] * f; SY += r[3] * f; SZ += r[1] * f * cz;
+                }
+            }
+        AccT* o = partials + (((size_t)img * slabs + slab) * nj + j) * 5;
+        o[0] = M; o[1] = S; o[2] = SX; o[3] = SY; o[4] = SZ;
+    }
+}
+
+template <typename AccT>
+__global__ __launch_bounds__(64) void softargmax_finalize_kernel(const AccT* __restrict__ partials,
+                                                                 float* __restrict__ poses,
+                                                                 SoftArgmaxArgs a, int slabs) {
+    __shared__ AccT mm[METRO_MAX_JOINTS][3];
+    const int img = blockIdx.x;
+    const int j = threadIdx.x;
+    const int nj = a.n_joints_head;
+    if (j < nj) {
+        AccT M = (AccT)-INFINITY;
+        for (int sl = 0; sl < slabs; ++sl) {
+            const AccT mv = partials[(((size_t)img * slabs + sl) * nj + j) * 5];
+            M = mv > M ? mv : M;
+        }
+        AccT S = 0, SX = 0, SY = 0, SZ = 0;
+        for (int sl = 0; sl < slabs; ++sl) {
+            const AccT* r = partials + (((size_t)img * slabs + sl) * nj + j) * 5;
+            if (r[1] > 0) {
+                const AccT f = acc_exp<AccT>(r[0] - M);
+                S += r[1] * f; SX += r[2] * f; SY += r[3] * f; SZ += r[4] * f;
+            }
+        }
+        const AccT x01 = SX / S, y01 = SY / S, z01 = SZ / S;
+        // heatmap_to_metric: (c * lrc + half) * box / proc_side ; z * box  (volumetric.py:288-306)
+        mm[j][0] = (x01 * (AccT)a.lrc + (AccT)a.half_off) * (AccT)a.box_size_mm / (AccT)a.proc_side;
+        mm[j][1] = (y01 * (AccT)a.lrc + (AccT)a.half_off) * (AccT)a.box_size_mm / (AccT)a.proc_side;
+        mm[j][2] = z01 * (AccT)a.box_size_mm;
+    }
+    __syncthreads();
+    if (j < a.n_joints_out) {
+        const int src = a.perm[j];
+        float* o = poses + ((size_t)img * a.n_joints_out + j) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = (float)(mm[src][c] - mm[nj - 1][c]);   // tfu3d.py:23-25
+    }
+}
+
+SoftArgmaxArgs make_softargmax_args(const MetroSpec& spec, int n) {
+    SoftArgmaxArgs a;
+    a.n = n;
+    a.side = spec.proc_side / spec.stride;
+    a.depth = spec.depth;
+    a.n_joints_head = spec.n_joints_head;
+    a.n_joints_out = spec.n_joints_out;
+    const int last = spec.proc_side - 1;
+    a.lrc = last - (last % spec.stride) - 1;                        // volumetric.py:290-291
+    a.half_off = spec.centered_stride ? spec.stride / 2 : 0;             // volumetric.py:293-294
+    a.box_size_mm = spec.box_size_mm;
+    a.proc_side = spec.proc_side;
+    for (int i = 0; i < METRO_MAX_JOINTS; ++i) a.perm[i] = i < spec.n_joints_out ? spec.permutation[i] : 0;
+    return a;
+}
+
+template <typename AccT>
+static int launch_softargmax_t(const float* logits, const SoftArgmaxArgs& a, void* partials,
+                               float* poses, hipStream_t stream) {
+    const int C = a.depth * a.n_joints_head;
+    const int quads = C / 4;
+    const int ppb = SA_NT / quads;
+    const int slabs = softargmax_slabs(a.n, a.side);
+    const size_t lds = (size_t)ppb * C * 4 * sizeof(AccT);
+    auto kern = softargmax_partial_kernel<AccT>;
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { set_error("hipFuncSetAttribute(softargmax): %s", hipGetErrorString(e)); return METRO_ERR_HIP; }
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(slabs, a.n), dim3(SA_NT), lds, stream, logits,
+                       static_cast<AccT*>(partials), a.side, a.depth, a.n_joints_head, slabs);
+    int st = launch_status("softargmax_partial");
+    if (st) return st;
+    hipLaunchKernelGGL(softargmax_finalize_kernel<AccT>, dim3(a.n), dim3(64), 0, stream,
+                       static_cast<const AccT*>(partials), poses, a, slabs);
+    return launch_status("softargmax_finalize");
+}
+
+int launch_softargmax(const float* logits, const SoftArgmaxArgs& a, bool precise, void* partials,
+                      float* poses_out, hipStream_t stream) {
+    const int C = a.depth * a.n_joints_head;
+    if (C % 4 || C / 4 > SA_NT || a.n_joints_head > METRO_MAX_JOINTS || a.n_joints_out > 64) {
+        set_error("softargmax: unsupported head (depth %d, joints %d)", a.depth, a.n_joints_head);
+        return METRO_ERR_UNSUPPORTED;
+    }
+    return precise ? launch_softargmax_t<double>(logits, a, partials, poses_out, stream)
+                   : launch_softargmax_t<float>(logits, a, partials, poses_out, stream);
+}
+
+}  // namespace metro

@@ -1,0 +1,60 @@
+"""Batch sharding of the hot path over the GPUs of one node (one process per GPU).
+
+No op of the path mixes images (BatchNorm is inference-mode, reference architectures.py:32;
+softmax is per (image, joint), volumetric.py:233), so a batch shards by image with replicated
+weights and NO activation exchange.  The only collective is one all-gather of the pose outputs
+([N/G, Jout, 3] fp32, <= 15 KB per rank: latency-bound), RCCL over xGMI when the process group
+is `nccl`, gloo in the CPU tests.  Results are bit-identical to the single-GPU run.
+(The reference has no multi-GPU code at all; this is defined by BASELINE.json's north star.)
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous chunk [begin, end) of rank `rank`; the first n % world ranks get one extra."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f'bad rank/world {rank}/{world}')
+    q, r = divmod(n, world)
+    begin = rank * q + min(rank, r)
+    return begin, begin + q + (1 if rank < r else 0)
+
+
+def all_gather_poses(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessGroup] = None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gathers the per-rank [n_r, J, 3] outputs (contiguous shards, rank order) into [n_total, J, 3]."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    j, c = local.shape[1], local.shape[2]
+    if out is None:
+        out = torch.empty((n_total, j, c), dtype=local.dtype, device=local.device)
+    if n_total % world == 0:
+        if local.shape[0] != n_total // world:
+            raise ValueError(f'rank {rank}: local batch {local.shape[0]} != {n_total // world}')
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)   # one ncclAllGather
+        return out
+    # ragged tail: pad every shard to the largest, gather, then compact
+    q = -(-n_total // world)
+    padded = torch.zeros((q, j, c), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    buf = torch.empty((world * q, j, c), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    for r in range(world):
+        b, e = shard_range(n_total, r, world)
+        out[b:e] = buf[r * q: r * q + (e - b)]
+    return out
+
+
+def sharded_forward(forward_fn: Callable[[torch.Tensor], torch.Tensor], images: torch.Tensor,
+                    group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """Every rank holds the same global batch `images`; rank r runs `forward_fn` on its contiguous
+    shard and all ranks return the full [N, J, 3] result."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    b, e = shard_range(images.shape[0], rank, world)
+    local = forward_fn(images[b:e])
+    return all_gather_poses(local, images.shape[0], group)

@@ -1,0 +1,120 @@
+"""Drop-in for the reference's `inference.py` (reference inference.py:11-43).
+
+Same call: `estimate_pose(images_tensor, model_path) -> (poses, joint_edges, joint_names)`,
+same CLI flag `--model-path`.  Differences that follow from not being TensorFlow:
+  * eager: `poses` is a float32 torch.Tensor [N, Jout, 3] (mm, root-relative) on the GPU, already
+    computed (the reference returns graph tensors to `sess.run` later, inference.py:25-27);
+  * `joint_edges` is an int64 ndarray [E, 2] and `joint_names` an object ndarray of `bytes`,
+    which is what `sess.run` yields for those constants (main.py:140-141);
+  * `model_path` is the container of modelfile.py (the `.pb` importer is SURVEY row f1).
+Input contract (inference.py:17-18, main.py:109-110): float32 NHWC [N,256,256,3], RGB in [0,1].
+The arithmetic mode defaults to fp16, the reference's default compute dtype (options.py:73);
+pass precision='f32' (or METRO_PRECISION=f32) for the parity mode.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from metro_pose3d_amd import _lib
+from metro_pose3d_amd.engine import Engine
+from metro_pose3d_amd.modelfile import load_model
+
+_ENGINES: Dict[Tuple[str, float, str, int], Engine] = {}
+DEFAULT_MAX_BATCH = 64
+
+
+def _engine_for(model_path: str, precision: str, device: torch.device) -> Engine:
+    path = os.path.abspath(model_path)
+    key = (path, os.path.getmtime(path), precision, device.index or 0)
+    eng = _ENGINES.get(key)
+    if eng is None:
+        spec, params = load_model(path)
+        eng = Engine(spec, params, precision=precision, max_batch=DEFAULT_MAX_BATCH, device=device)
+        _ENGINES[key] = eng
+    return eng
+
+
+def estimate_pose(images_tensor, model_path, precision: Optional[str] = None):
+    """images [N,256,256,3] float32 in [0,1] -> (poses [N,Jout,3] mm, joint_edges, joint_names)."""
+    if precision is None:
+        precision = os.environ.get('METRO_PRECISION', 'f16')
+    if not torch.cuda.is_available():
+        raise _lib.MetroError('no HIP device visible: the MeTRo hot path has no CPU fallback')
+    if isinstance(images_tensor, np.ndarray):
+        images_tensor = torch.from_numpy(images_tensor)
+    if not isinstance(images_tensor, torch.Tensor):
+        raise ValueError(f'images must be a torch.Tensor or numpy array, got {type(images_tensor)}')
+    if images_tensor.dtype != torch.float32:
+        raise ValueError(f'images must be float32 in [0,1] (reference inference.py:18), got {images_tensor.dtype}')
+    device = images_tensor.device if images_tensor.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    eng = _engine_for(model_path, precision, device)
+    s = eng.spec.proc_side
+    if images_tensor.dim() != 4 or tuple(images_tensor.shape[1:]) != (s, s, 3):
+        raise ValueError(f'images must be NHWC [N,{s},{s},3] (reference main.py:109-110), got '
+                         f'{tuple(images_tensor.shape)}')
+    images = images_tensor.to(device, non_blocking=True).contiguous()
+    n = images.shape[0]
+    sk = eng.spec.skeleton
+    poses = torch.empty((n, sk.n_out, 3), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        for i in range(0, n, eng.max_batch):
+            eng.forward(images[i:i + eng.max_batch], out=poses[i:i + eng.max_batch])
+    names = np.empty(sk.n_out, dtype=object)
+    names[:] = sk.names_bytes()
+    return poses, sk.edges_array(), names
+
+
+def visualize_pose(image, coords, edges):
+    """Stick-figure plot like reference inference.py:46-76 (matplotlib optional)."""
+    import matplotlib
+    matplotlib.use(os.environ.get('MPLBACKEND', 'Agg'))
+    import matplotlib.pyplot as plt
+    from mpl_toolkits.mplot3d import Axes3D  # noqa: F401
+
+    pts = np.asarray(coords, dtype=np.float64)
+    # camera frame has y down / z forward; matplotlib wants z up (reference inference.py:52-56)
+    plot_pts = np.stack([pts[:, 0], pts[:, 2], -pts[:, 1]], axis=1)
+    fig = plt.figure(figsize=(10, 5))
+    ax_im = fig.add_subplot(1, 2, 1)
+    ax_im.set_title('Input')
+    ax_im.imshow(np.clip(np.asarray(image), 0, 1))
+    ax = fig.add_subplot(1, 2, 2, projection='3d')
+    ax.set_title('Prediction')
+    lim = 800
+    ax.set_xlim3d(-lim, lim); ax.set_ylim3d(-lim, lim); ax.set_zlim3d(-lim, lim)
+    for a, b in np.asarray(edges):
+        ax.plot(*zip(plot_pts[a], plot_pts[b]), marker='o', markersize=2)
+    ax.scatter(plot_pts[:, 0], plot_pts[:, 1], plot_pts[:, 2], s=2)
+    fig.tight_layout()
+    return fig
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description='MeTRo-Pose3D on MI355X', allow_abbrev=False)
+    parser.add_argument('--model-path', type=str, required=True)
+    parser.add_argument('--image', type=str, default=None,
+                        help='.npy file with a [256,256,3] float image in [0,1]; default: seeded noise')
+    parser.add_argument('--precision', type=str, default=None, choices=['f16', 'f32'])
+    parser.add_argument('--plot', type=str, default=None, help='write the stick-figure plot to this file')
+    opts = parser.parse_args(argv)
+    if opts.image:
+        img = np.load(opts.image).astype(np.float32)
+    else:
+        from metro_pose3d_amd.synth import make_images
+        img = make_images(1)[0]
+    images = torch.from_numpy(img[None])
+    poses, edges, names = estimate_pose(images, opts.model_path, precision=opts.precision)
+    poses = poses.cpu().numpy()
+    for name, p in zip(names, poses[0]):
+        print(f'{name.decode():>10s}  {p[0]:9.2f} {p[1]:9.2f} {p[2]:9.2f}')
+    if opts.plot:
+        visualize_pose(img, poses[0], edges).savefig(opts.plot)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,185 @@
+"""Model spec, unit schedule, decode constants and joint tables of the exported graph.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Restates, independently of the product's C++
+planner (metro_pose3d_amd/csrc/plan.cpp), the control flow of:
+  * reference src/model/resnet_v2.py:272-312   (block tables, which unit is "centered")
+  * reference src/model/resnet_utils.py:307-348 (stack_blocks_dense: stride/rate schedule)
+  * reference src/model/volumetric.py:288-295   (decode constants)
+  * reference src/data/datasets.py:52-109, src/data/h36m.py:25-31, src/main.py:119-141
+    (joint names, edges, export permutation)
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import List, Sequence, Tuple
+
+
+@dataclasses.dataclass(frozen=True)
+class OracleSpec:
+    arch: int = 50                 # 50 | 101           (options.py:109-111)
+    stride: int = 16               # 4 | 8 | 16 | 32    (options.py:96, README.md:26-28)
+    dataset: str = 'h36m'          # 'h36m' | 'merged' | 'many19' (head = output = 19 joints)
+    depth: int = 8                 # options.py:113
+    centered_stride: bool = True   # options.py:118
+    proc_side: int = 256           # options.py:41
+    box_size_mm: float = 2200.0    # options.py:119
+    base_width: int = 64           # 64 = real ResNet; smaller = toy spec for fixtures
+
+    @property
+    def arch_name(self) -> str:
+        return f'resnet_v2_{self.arch}'
+
+    @property
+    def out_side(self) -> int:
+        return self.proc_side // self.stride
+
+
+@dataclasses.dataclass(frozen=True)
+class Unit:
+    block: int          # 1..4
+    unit: int           # 1-based within block
+    c_in: int
+    c_out: int          # 4 * c_bott
+    c_bott: int
+    stride: int         # stride actually executed (after the atrous scheduler)
+    rate: int           # dilation actually executed
+    centered: bool      # the unit's centered_stride flag (only matters when stride == 2)
+    side_in: int
+    side_out: int
+
+    @property
+    def name(self) -> str:
+        return f'block{self.block}/unit_{self.unit}'
+
+
+def block_table(spec: OracleSpec) -> List[Tuple[int, int, int, bool]]:
+    """[(base_depth, num_units, block_stride, centered_flag)] -- resnet_v2.py:272-312."""
+    c = [False, False, False]
+    if spec.centered_stride:
+        if spec.arch == 50:
+            # resnet_v2.py:279-281 (np.round, guarded against negative index)
+            i_last = int(round(math.log2(spec.stride))) - 3
+            if i_last >= 0:
+                c[i_last] = True
+        else:
+            # resnet_v2.py:301-302 (int(), NOT guarded: c[-1] at stride 4 marks block3, a no-op)
+            i_last = int(math.log2(spec.stride)) - 3
+            c[i_last] = True
+    n3 = {50: 6, 101: 23}[spec.arch]
+    w = spec.base_width
+    return [(w, 3, 2, c[0]), (2 * w, 4, 2, c[1]), (4 * w, n3, 2, c[2]), (8 * w, 3, 1, False)]
+
+
+def schedule(spec: OracleSpec) -> List[Unit]:
+    """Per-unit (stride, rate) as run by stack_blocks_dense (resnet_utils.py:307-348)."""
+    if spec.stride % 4 != 0:
+        raise ValueError('The output_stride needs to be a multiple of 4.')  # resnet_v2.py:213-214
+    output_stride = spec.stride / 4           # float on purpose (resnet_v2.py:215)
+    current_stride = 1
+    rate = 1
+    side = spec.proc_side // 4                 # after conv1 (/2) and pool1 (/2)
+    c_in = spec.base_width                     # conv1 emits `base_width` channels (64)
+    units: List[Unit] = []
+    for b, (base, n_units, block_stride, centered) in enumerate(block_table(spec), start=1):
+        for u in range(1, n_units + 1):
+            # resnet_v2.py:260-269: stride sits on the LAST unit, which also carries `centered`
+            unit_stride = block_stride if u == n_units else 1
+            unit_centered = centered if u == n_units else False
+            if current_stride == output_stride:
+                run_stride, run_rate = 1, rate                 # resnet_utils.py:325-327
+                rate *= unit_stride
+            else:
+                run_stride, run_rate = unit_stride, 1          # resnet_utils.py:329-333
+                current_stride *= unit_stride
+                if current_stride > output_stride:
+                    raise ValueError('The target output_stride cannot be reached.')
+            side_out = side // run_stride if run_stride == 2 else side
+            units.append(Unit(b, u, c_in, 4 * base, base, run_stride, run_rate, unit_centered,
+                              side, side_out))
+            side = side_out
+            c_in = 4 * base
+    if current_stride != output_stride:
+        raise ValueError('The target output_stride cannot be reached.')
+    return units
+
+
+def decode_constants(spec: OracleSpec) -> Tuple[int, int]:
+    """(last_receptive_center, half_stride_offset) -- volumetric.py:288-295."""
+    last_image_pixel = spec.proc_side - 1
+    lrc = last_image_pixel - (last_image_pixel % spec.stride) - 1
+    half = spec.stride // 2 if spec.centered_stride else 0
+    return lrc, half
+
+
+# ----------------------------------------------------------------------------------------------
+# Joint tables (restating JointInfo, datasets.py:52-109)
+# ----------------------------------------------------------------------------------------------
+def _pairwise(seq: Sequence[str]):
+    return zip(seq[:-1], seq[1:])
+
+
+class OracleJointInfo:
+    def __init__(self, names: Sequence[str], edges):
+        self.names = list(names)
+        ids = {n: i for i, n in enumerate(self.names)}
+        if isinstance(edges, str):                       # datasets.py:66-73
+            self.edges = []
+            for path in edges.split(','):
+                for a, b in _pairwise(path.split('-')):
+                    if a in ids and b in ids:
+                        self.edges.append((ids[a], ids[b]))
+        else:
+            self.edges = [tuple(e) for e in edges]
+        self.n_joints = len(self.names)
+
+    def permute(self, permutation: Sequence[int]) -> 'OracleJointInfo':
+        """datasets.py:104-108 with util.invert_permutation (util.py:483-484).
+
+        For a *partial* permutation (merged: 19 of 53) argsort-based inversion is only
+        meaningful for the gathered joints; all reference edges are among those."""
+        order = sorted(range(len(permutation)), key=lambda i: permutation[i])
+        inv = {permutation[i]: i for i in order}
+        new_names = [self.names[p] for p in permutation]
+        new_edges = [(inv[i], inv[j]) for i, j in self.edges]
+        return OracleJointInfo(new_names, new_edges)
+
+
+def head_joint_info(dataset: str) -> OracleJointInfo:
+    if dataset == 'h36m':                                # h36m.py:25-31
+        names = ('rhip,rkne,rank,lhip,lkne,lank,tors,neck,head,htop,'
+                 'lsho,lelb,lwri,rsho,relb,rwri,pelv').split(',')
+        edges = ('htop-head-neck-lsho-lelb-lwri,neck-rsho-relb-rwri,'
+                 'neck-tors-pelv-lhip-lkne-lank,pelv-rhip-rkne-rank')
+        return OracleJointInfo(names, edges)
+    if dataset in ('merged', 'many19'):                  # datasets.py:142-154
+        names = ['neck', 'nose', 'lsho', 'lelb', 'lwri', 'lhip', 'lkne', 'lank', 'rsho', 'relb',
+                 'rwri', 'rhip', 'rkne', 'rank', 'leye', 'lear', 'reye', 'rear', 'pelv',
+                 'htop_tdhp', 'neck_tdhp', 'rsho_tdhp', 'lsho_tdhp', 'rhip_tdhp', 'lhip_tdhp',
+                 'spin_tdhp', 'head_tdhp', 'pelv_tdhp', 'rhip_h36m', 'lhip_h36m', 'tors_h36m',
+                 'neck_h36m', 'head_h36m', 'htop_h36m', 'lsho_h36m', 'rsho_h36m', 'pelv_h36m',
+                 'lhip_tdpw', 'rhip_tdpw', 'bell_tdpw', 'che1_tdpw', 'che2_tdpw', 'ltoe_tdpw',
+                 'rtoe_tdpw', 'neck_tdpw', 'lcla_tdpw', 'rcla_tdpw', 'head_tdpw', 'lsho_tdpw',
+                 'rsho_tdpw', 'lhan_tdpw', 'rhan_tdpw', 'pelv_tdpw']
+        edges = [(1, 0), (0, 18), (0, 2), (2, 3), (3, 4), (0, 8), (8, 9), (9, 10), (18, 5),
+                 (5, 6), (6, 7), (18, 11), (11, 12), (12, 13), (15, 14), (14, 1), (17, 16),
+                 (16, 1)]
+        if dataset == 'many19':
+            # BASELINE.json's "19-joint COCO/CMU" configs: a head that emits exactly the 19
+            # exported joints (README.md:27-28), i.e. the first 19 names of `merged`.
+            return OracleJointInfo(names[:19], edges)
+        return OracleJointInfo(names, edges)
+    raise ValueError(f'unknown dataset {dataset!r}')
+
+
+def export_permutation(dataset: str) -> List[int]:
+    """main.py:119-125."""
+    if dataset in ('merged', 'many19'):
+        return [0, 1, 18, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17]
+    if dataset == 'h36m':
+        return [16, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]
+    raise ValueError(f'no export permutation restated for dataset {dataset!r}')
+
+
+def output_joint_info(dataset: str) -> OracleJointInfo:
+    return head_joint_info(dataset).permute(export_permutation(dataset))

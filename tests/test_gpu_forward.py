@@ -1,0 +1,109 @@
+"""Whole-path parity on the GPU (`-m gpu`): metro_forward through the C ABI vs the fp64 oracle.
+
+Bars (BASELINE.json north star): parity mode (precision='f32') within 1e-3 mm of the oracle;
+fp16 mode is the reference's own default compute dtype (options.py:73) and is held to the
+tolerance its 11-bit activations allow, measured against the same oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from metro_pose3d_amd import ModelSpec, _lib, synth
+from metro_pose3d_amd.engine import Engine
+from oracle import forward as OF
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32_MM = 1e-3
+TOY = [ModelSpec(50, 32, 'h36m', base_width=8), ModelSpec(50, 16, 'many19', base_width=8),
+       ModelSpec(50, 8, 'h36m', base_width=8), ModelSpec(50, 4, 'h36m', base_width=8),
+       ModelSpec(101, 8, 'merged', base_width=8), ModelSpec(101, 4, 'many19', base_width=8),
+       ModelSpec(50, 16, 'h36m', base_width=16, centered_stride=False)]
+_id = lambda s: f'rn{s.arch}-s{s.stride}-{s.dataset}-w{s.base_width}' + ('' if s.centered_stride else '-nc')
+
+
+def _setup(spec, n, gain=3.0, seed=0):
+    params = synth.make_params(spec.arch, spec.n_head_channels, spec.base_width, seed=seed, logit_gain=gain)
+    images = synth.make_images(n, spec.proc_side)
+    return params, images
+
+
+@pytest.mark.parametrize('spec', TOY, ids=_id)
+def test_toy_forward_f32_within_1e3_mm(cuda, spec):
+    params, images = _setup(spec, 3)
+    ref = OF.forward(H.oracle_spec(spec), params, images, torch.float64).numpy()
+    eng = Engine(spec, params, 'f32', max_batch=4, device=cuda)
+    got = eng.forward(torch.from_numpy(images).to(cuda)).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= TOL_F32_MM, np.abs(got - ref).max()
+
+
+@pytest.mark.parametrize('spec', TOY[:3], ids=_id)
+def test_toy_layerwise(cuda, spec):
+    """Every layer output of both precision modes against the oracle's intermediate tensors."""
+    params, images = _setup(spec, 2)
+    col = {}
+    OF.forward(H.oracle_spec(spec), params, images, torch.float64, col)
+    x = torch.from_numpy(images).to(cuda)
+    for prec, rel in (('f32', 2e-6), ('f16', 3e-2)):
+        eng = Engine(spec, params, prec, max_batch=2, device=cuda)
+        for i, li in enumerate(eng.layer_infos()):
+            name = li.name.decode()
+            key = {'logits': 'logits', 'conv1': 'conv1', 'pool1': 'pool1'}.get(name)
+            if key is None and name.endswith('/conv3'):
+                key = name[:-len('/conv3')]                  # unit output = shortcut + conv3
+            elif key is None and name.endswith(('/conv1', '/conv2')):
+                key = name
+            if key is None or key not in col:
+                continue
+            got = eng.forward_upto(x, i).float().cpu().double().numpy()
+            ref = col[key].permute(0, 2, 3, 1).numpy()
+            err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+            assert err <= rel, (prec, name, err)
+
+
+def test_full_rn50_s16_f32_and_f16(cuda):
+    spec = ModelSpec(50, 16, 'h36m')
+    params, images = _setup(spec, 2, gain=synth.logit_gain_for(50, 16))
+    ref = OF.forward(H.oracle_spec(spec), params, images, torch.float64).numpy()
+    x = torch.from_numpy(images).to(cuda)
+    got32 = Engine(spec, params, 'f32', max_batch=2, device=cuda).forward(x).cpu().numpy()
+    assert np.abs(got32 - ref).max() <= TOL_F32_MM, np.abs(got32 - ref).max()
+    got16 = Engine(spec, params, 'f16', max_batch=2, device=cuda).forward(x).cpu().numpy()
+    assert np.isfinite(got16).all()
+    # fp16 activations (rel 5e-4 per layer over 50+ layers) -> logits off by ~1e-2 -> a few mm
+    assert np.abs(got16 - ref).max() <= 25.0, np.abs(got16 - ref).max()
+    assert np.abs(got16 - ref).mean() <= 5.0
+
+
+def test_batch_independence_bit_exact(cuda):
+    """No op crosses the batch dimension: a batch and its halves give identical bits."""
+    spec = ModelSpec(50, 16, 'h36m', base_width=16)
+    params, images = _setup(spec, 6)
+    x = torch.from_numpy(images).to(cuda)
+    for prec in ('f16', 'f32'):
+        eng = Engine(spec, params, prec, max_batch=8, device=cuda)
+        whole = eng.forward(x).clone()
+        parts = torch.cat([eng.forward(x[:2]).clone(), eng.forward(x[2:]).clone()])
+        assert torch.equal(whole, parts)
+
+
+def test_estimate_pose_boundary(cuda, tmp_path):
+    """Same call shape as reference inference.py:31-43."""
+    from metro_pose3d_amd import save_model
+    from metro_pose3d_amd.inference import estimate_pose
+    spec = ModelSpec(50, 32, 'h36m', base_width=8)
+    params, images = _setup(spec, 2)
+    path = str(tmp_path / 'toy.npz')
+    save_model(path, spec, params)
+    poses, edges, names = estimate_pose(images, path, precision='f32')
+    assert poses.shape == (2, 17, 3) and poses.dtype == torch.float32 and poses.is_cuda
+    assert edges.dtype == np.int64 and edges.shape == (16, 2)
+    assert names[0] == b'pelv' and len(names) == 17
+    ref = OF.forward(H.oracle_spec(spec), params, images, torch.float64).numpy()
+    assert np.abs(poses.cpu().numpy() - ref).max() <= TOL_F32_MM
+    with pytest.raises(ValueError):
+        estimate_pose(images[:, :128], path)
+    with pytest.raises(ValueError):
+        estimate_pose(images.astype(np.float64), path)

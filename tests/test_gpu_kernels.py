@@ -1,0 +1,237 @@
+"""Single-kernel parity through the C ABI (`-m gpu`): HIP kernels vs fp64 references built from
+the oracle's padding / pooling / soft-argmax restatements on the same seeded inputs."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from metro_pose3d_amd import ModelSpec, _lib
+from metro_pose3d_amd._lib import check
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+# (name, n, h_in, c_in, c_out, k, stride, dil, pad, h_out)
+# pads follow reference resnet_utils.py:120-135: SAME (rate r -> pad r; centered stride-2 -> 0)
+# or explicit (k_eff-1)//2.
+CONV_CASES = [
+    ('1x1', 2, 16, 64, 256, 1, 1, 1, 0, 16),
+    ('1x1_ragged_m', 3, 7, 64, 64, 1, 1, 1, 0, 7),
+    ('1x1_head136', 2, 16, 128, 136, 1, 1, 1, 0, 16),
+    ('1x1_cin_tail', 2, 8, 24, 64, 1, 1, 1, 0, 8),
+    ('3x3_s1', 2, 16, 64, 64, 3, 1, 1, 1, 16),
+    ('3x3_rate2', 2, 16, 64, 128, 3, 1, 2, 2, 16),
+    ('3x3_rate4', 1, 32, 32, 64, 3, 1, 4, 4, 32),
+    ('3x3_rate8', 1, 16, 32, 64, 3, 1, 8, 8, 16),
+    ('3x3_s2_explicit', 2, 32, 64, 64, 3, 2, 1, 1, 16),
+    ('3x3_s2_centered', 2, 32, 64, 64, 3, 2, 1, 0, 16),
+    ('3x3_big', 4, 32, 128, 256, 3, 1, 1, 1, 32),
+    ('1x1_s2_shifted', 2, 16, 64, 128, 1, 2, 1, -1, 8),
+]
+
+
+def _mk(rng, n, h_in, c_in, c_out, k):
+    x = rng.standard_normal((n, h_in, h_in, c_in)).astype(np.float32)
+    w = (rng.standard_normal((c_out, k, k, c_in)) * np.sqrt(2.0 / (k * k * c_in))).astype(np.float32)
+    b = (rng.standard_normal(c_out) * 0.1).astype(np.float32)
+    return x, w, b
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize('variant', ['plain', 'relu', 'prologue', 'residual', 'f32out'])
+def test_conv_f16(lib, cuda, case, variant):
+    name, n, h_in, c_in, c_out, k, stride, dil, pad, h_out = case
+    if variant == 'prologue' and (k != 1 or pad > 0):
+        pytest.skip('prologue is defined for un-padded 1x1 convs only')
+    rng = np.random.default_rng(zlib.crc32(f'{name}/{variant}'.encode()))
+    x, w, b = _mk(rng, n, h_in, c_in, c_out, k)
+    x16, w16 = x.astype(np.float16), w.astype(np.float16)
+    pro = res = None
+    if variant == 'prologue':
+        pro = (rng.uniform(0.5, 1.5, c_in).astype(np.float16), (rng.standard_normal(c_in) * 0.2).astype(np.float16))
+    if variant == 'residual':
+        res = rng.standard_normal((n, h_out, h_out, c_out)).astype(np.float16)
+    d = H.conv_desc(n, h_in, c_in, h_out, c_out, k, stride, dil, pad, prologue=pro is not None,
+                    relu=variant == 'relu', residual=res is not None, res_h=h_out,
+                    out_dtype=_lib.METRO_F32 if variant == 'f32out' else _lib.METRO_F16)
+    got = H.run_conv_f16(lib, cuda, d, x16, w16, b, pro, res).astype(np.float64)
+    if pro is not None:
+        # the kernel applies relu(x*s+b) with ONE fp16 rounding (v_pk_fma_f16): mirror it
+        xin = np.maximum(np.float16(x16.astype(np.float64) * pro[0].astype(np.float64) + pro[1].astype(np.float64)), 0)
+        ref = H.ref_conv_nhwc(xin.astype(np.float64), w16, b, stride, dil, pad, h_out, relu=False).numpy()
+    else:
+        ref = H.ref_conv_nhwc(x16, w16, b, stride, dil, pad, h_out, relu=variant == 'relu', res=res).numpy()
+    assert np.isfinite(got).all()
+    scale = np.abs(ref).max()
+    tol = (2e-3 if d.out_dtype == _lib.METRO_F16 else 2e-5) * scale   # fp16 output rounding / fp32 accumulation
+    assert np.abs(got - ref).max() <= tol, (np.abs(got - ref).max(), scale)
+
+
+@pytest.mark.parametrize('res_stride,res_offset', [(2, 0), (2, 1)])
+def test_conv_f16_strided_residual(lib, cuda, res_stride, res_offset):
+    """identity shortcut of a strided unit: even pixels (non-centered) or odd pixels
+    (centered, x[1:,1:][::2,::2]) -- reference resnet_v2.py:113-121, resnet_utils.py:76-79 (KA8)."""
+    rng = np.random.default_rng(5 + res_offset)
+    n, h, c_in, c_out = 2, 8, 64, 128
+    x, w, b = _mk(rng, n, h, c_in, c_out, 1)
+    res = rng.standard_normal((n, 2 * h, 2 * h, c_out)).astype(np.float16)
+    d = H.conv_desc(n, h, c_in, h, c_out, 1, residual=True, res_h=2 * h, res_stride=res_stride,
+                    res_offset=res_offset)
+    got = H.run_conv_f16(lib, cuda, d, x, w, b, res=res).astype(np.float64)
+    ref = H.ref_conv_nhwc(x.astype(np.float16), w.astype(np.float16), b, 1, 1, 0, h, res=res,
+                          res_stride=res_stride, res_offset=res_offset).numpy()
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize('variant', ['plain', 'relu_residual', 'prologue'])
+def test_conv_f64acc(lib, cuda, case, variant):
+    name, n, h_in, c_in, c_out, k, stride, dil, pad, h_out = case
+    if variant == 'prologue' and (k != 1 or pad > 0):
+        pytest.skip('prologue is defined for un-padded 1x1 convs only')
+    rng = np.random.default_rng(zlib.crc32(f'{name}/{variant}/64'.encode()))
+    x, w, b = _mk(rng, n, h_in, c_in, c_out, k)
+    w = w.astype(np.float64) * (1 + 1e-9)    # genuinely fp64 weights
+    pro = res = None
+    if variant == 'prologue':
+        pro = (rng.uniform(0.5, 1.5, c_in), rng.standard_normal(c_in) * 0.2)
+    if variant == 'relu_residual':
+        res = rng.standard_normal((n, h_out, h_out, c_out)).astype(np.float32)
+    d = H.conv_desc(n, h_in, c_in, h_out, c_out, k, stride, dil, pad, prologue=pro is not None,
+                    relu=variant == 'relu_residual', residual=res is not None, res_h=h_out,
+                    out_dtype=_lib.METRO_F32)
+    got = H.run_conv_f64acc(lib, cuda, d, x, w, b.astype(np.float64), pro, res).astype(np.float64)
+    ref = H.ref_conv_nhwc(x, w, b.astype(np.float64), stride, dil, pad, h_out, pro=pro,
+                          relu=variant == 'relu_residual', res=res).numpy()
+    # fp64 accumulation, one rounding to fp32: at most 1 ulp of the result (plus reordering ~1e-15)
+    err = np.abs(got - ref)
+    ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    assert (err <= 0.5001 * ulp + 1e-12).all(), (err / ulp).max()
+
+
+def test_conv_f64acc_stem_3ch(lib, cuda):
+    """7x7/2 stem on the raw 3-channel image with TF explicit pad 3 (resnet_utils.py:125-135)."""
+    from oracle.forward import conv2d_same
+    rng = np.random.default_rng(7)
+    x = rng.random((2, 64, 64, 3)).astype(np.float32)
+    w_hwio = (rng.standard_normal((7, 7, 3, 16)) * 0.1)
+    b = rng.standard_normal(16) * 0.01
+    d = H.conv_desc(2, 64, 3, 32, 16, 7, stride=2, pad=3, out_dtype=_lib.METRO_F32)
+    got = H.run_conv_f64acc(lib, cuda, d, x, w_hwio.transpose(3, 0, 1, 2), b)
+    ref = conv2d_same(torch.from_numpy(x).double().permute(0, 3, 1, 2),
+                      torch.from_numpy(w_hwio).permute(3, 2, 0, 1), 2, 1, False).permute(0, 2, 3, 1).numpy() + b
+    assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max()
+
+
+def test_stem_f16_via_bordered_image(lib, cuda):
+    """prep_input + 7x1-tap conv over the bordered 4-channel image == conv2d_same 7x7/2 pad 3."""
+    from oracle.forward import conv2d_same
+    rng = np.random.default_rng(8)
+    n, side, co = 2, 64, 64
+    x = rng.random((n, side, side, 3)).astype(np.float32)
+    w_hwio = (rng.standard_normal((7, 7, 3, co)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.01).astype(np.float32)
+    tx = torch.from_numpy(x).to(cuda)
+    prep = torch.full((n, side + 6, side + 8, 4), float('nan'), dtype=torch.float16, device=cuda)
+    check(lib.metro_prep_input_f16(H.ptr(tx), n, side, H.ptr(prep), C.c_void_p(0)), 'prep')
+    torch.cuda.synchronize()
+    p = prep.cpu().numpy()
+    exp = np.zeros((n, side + 6, side + 8, 4), np.float16)
+    exp[:, 3:3 + side, 3:3 + side, :3] = x.astype(np.float16)
+    assert np.array_equal(p, exp)
+    packed = np.zeros((co, 7, 8, 4), np.float16)
+    packed[:, :, :7, :3] = w_hwio.transpose(3, 0, 1, 2).astype(np.float16)
+    d = H.conv_desc(n, side + 6, 32, side // 2, co, 0, stride=2, pad=0, w_in=side + 8, in_pix_stride=4,
+                    kh=7, kw=1)
+    got = H.run_conv_f16(lib, cuda, d, p, packed.reshape(co, 7, 1, 32), b).astype(np.float64)
+    ref = conv2d_same(torch.from_numpy(x.astype(np.float16)).double().permute(0, 3, 1, 2),
+                      torch.from_numpy(w_hwio.astype(np.float16)).double().permute(3, 2, 0, 1), 2, 1,
+                      False).permute(0, 2, 3, 1).numpy() + b
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('dtype', ['f16', 'f32'])
+def test_maxpool_zeropad(lib, cuda, dtype):
+    from oracle.forward import max_pool2d_same_zeropad
+    rng = np.random.default_rng(9)
+    tdt = torch.float16 if dtype == 'f16' else torch.float32
+    x = torch.from_numpy(rng.standard_normal((3, 32, 32, 64)).astype(np.float32)).to(tdt)
+    x[1] = -x[1].abs() - 0.5                       # KA7: all-negative image
+    out = torch.full((3, 16, 16, 64), float('nan'), dtype=tdt, device=cuda)
+    xd = x.to(cuda)
+    check(lib.metro_maxpool3x3s2_zeropad(H.ptr(xd), H.ptr(out), 3, 32, 32, 64,
+                                         _lib.METRO_F16 if dtype == 'f16' else _lib.METRO_F32,
+                                         C.c_void_p(0)), 'maxpool')
+    torch.cuda.synchronize()
+    ref = max_pool2d_same_zeropad(x.double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    got = out.cpu().double()
+    assert torch.equal(got, ref)                   # max is exact in any dtype
+    assert (got[1, 0, :, :] == 0).all() and (got[1, :, 0, :] == 0).all()   # border windows saw the pad
+    assert (got[1, 1:, 1:, :] < 0).all()
+
+
+SA_SPECS = [ModelSpec(50, 32, 'h36m'), ModelSpec(50, 16, 'h36m'), ModelSpec(50, 16, 'many19'),
+            ModelSpec(101, 8, 'merged'), ModelSpec(50, 4, 'h36m')]
+
+
+@pytest.mark.parametrize('spec', SA_SPECS, ids=lambda s: f'rn{s.arch}-s{s.stride}-{s.dataset}')
+@pytest.mark.parametrize('precise', [False, True])
+def test_softargmax_random(lib, cuda, spec, precise):
+    from oracle.forward import logits_to_output
+    rng = np.random.default_rng(spec.stride)
+    n, s, c = 3, spec.heatmap_side, spec.n_head_channels
+    logits = (rng.standard_normal((n, s, s, c)) * 4).astype(np.float32)
+    got = H.run_softargmax(lib, cuda, spec, logits, precise)
+    ref = logits_to_output(H.oracle_spec(spec), logits).numpy()
+    tol = 1e-3 if precise else 5e-2       # mm; fp32 accumulation of 8*S*S terms in fast mode
+    assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
+
+
+def test_softargmax_known_answers(lib, cuda):
+    """KA1 one-hot, KA2 uniform, KA3 shift invariance, KA5 channel order."""
+    spec = ModelSpec(50, 16, 'h36m')
+    sk = spec.skeleton
+    s, dd, j = spec.heatmap_side, spec.depth, sk.n_head
+    lrc, half = 239, 8
+    mm = lambda c01: (c01 * lrc + half) * 2200.0 / 256
+    logits = np.full((2, s, s, dd * j), -50.0, np.float32)
+    pos = {}
+    rng = np.random.default_rng(3)
+    for jj in range(j):
+        h, w, d_ = rng.integers(0, s), rng.integers(0, s), rng.integers(0, dd)
+        pos[jj] = (w, h, d_)
+        logits[0, h, w, d_ * j + jj] = 60.0                # channel = d*J + j (volumetric.py:231)
+    logits[1] = 1.25                                        # uniform
+    for precise in (False, True):
+        got = H.run_softargmax(lib, cuda, spec, logits, precise)
+        head = np.array([[mm(pos[jj][0] / (s - 1)), mm(pos[jj][1] / (s - 1)), pos[jj][2] / (dd - 1) * 2200.0]
+                         for jj in range(j)])
+        exp0 = (head - head[-1])[list(sk.permutation)]
+        assert np.abs(got[0] - exp0).max() < 1e-2
+        assert np.abs(got[1]).max() < 1e-3                 # all joints at the centre -> root-relative 0
+        shifted = H.run_softargmax(lib, cuda, spec, logits + 7.5, precise)
+        assert np.abs(shifted - got).max() < 1e-3
+    assert (got[:, 0, :] == 0).all()                        # h36m: output row 0 is the root (KA10)
+
+
+def test_softargmax_online_rescale_branch(lib, cuda):
+    """Monotonically increasing logits force the running-max rescale on every step."""
+    from oracle.forward import logits_to_output
+    spec = ModelSpec(50, 8, 'h36m')
+    s, c = spec.heatmap_side, spec.n_head_channels
+    base = np.arange(s * s, dtype=np.float32).reshape(1, s, s, 1) * 0.05
+    logits = np.broadcast_to(base, (1, s, s, c)).copy()
+    logits += np.random.default_rng(0).standard_normal(logits.shape).astype(np.float32) * 0.01
+    for precise in (False, True):
+        got = H.run_softargmax(lib, cuda, spec, logits, precise)
+        ref = logits_to_output(H.oracle_spec(spec), logits).numpy()
+        assert np.abs(got - ref).max() <= (1e-3 if precise else 5e-2)
+
+
+def test_error_reporting(lib):
+    d = H.conv_desc(1, 8, 12, 8, 64, 1)     # c_in not a multiple of 8
+    st = lib.metro_conv_f16(C.byref(d), C.c_void_p(256), C.c_void_p(256), C.c_void_p(256), None, None, None,
+                            C.c_void_p(256), None)
+    assert st == -1 and b'multiple of 8' in lib.metro_last_error()
