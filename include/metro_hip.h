@@ -35,13 +35,15 @@ typedef enum MetroStatus {
     METRO_ERR_STATE = -4
 } MetroStatus;
 
-/* Arithmetic mode of a plan.
+/* Arithmetic mode of a plan.  Images are always fp32 in, poses fp32 out.
  * F16: activations/weights fp16, fp32 MFMA accumulation, fp32 soft-argmax -- the reference's
- *      default compute dtype (reference src/options.py:73, src/tfu.py:426-440).
+ *      default compute dtype (reference src/options.py:73, src/tfu.py:426-440).  Throughput mode.
  * F32: activations fp32 in HBM, every contraction accumulated with v_mfma_f64_16x16x4_f64
  *      from fp64-folded weights, fp64 soft-argmax; one rounding to fp32 per layer output.
- *      This is the parity mode measured against the fp64 oracle (<= 1e-3 mm). */
-typedef enum MetroPrecision { METRO_PREC_F16 = 0, METRO_PREC_F32 = 1 } MetroPrecision;
+ *      Sits at the fp32 storage noise floor (~1e-3 mm vs exact arithmetic).
+ * F64: as F32 but activations and logits are stored as fp64 too: the parity mode, measured
+ *      against the fp64 oracle (bar <= 1e-3 mm; lands orders of magnitude below). */
+typedef enum MetroPrecision { METRO_PREC_F16 = 0, METRO_PREC_F32 = 1, METRO_PREC_F64 = 2 } MetroPrecision;
 
 typedef enum MetroDType { METRO_F16 = 0, METRO_F32 = 1, METRO_F64 = 2 } MetroDType;
 
@@ -150,7 +152,8 @@ typedef struct MetroConvDesc {
     int32_t has_residual;
     int32_t res_h, res_w;       /* spatial dims of the residual tensor [n,res_h,res_w,c_out] */
     int32_t res_stride, res_offset; /* residual pixel = (ho*res_stride+res_offset, wo*...)  */
-    int32_t out_dtype;          /* MetroDType: F16/F32 (fast kernel), F32 (precise kernel)  */
+    int32_t out_dtype;          /* MetroDType of output AND residual: F16/F32 (fast kernel), F32/F64 (precise kernel) */
+    int32_t in_dtype;           /* MetroDType of the input: F16 (fast kernel), F32/F64 (precise kernel) */
 } MetroConvDesc;
 
 /* fp16 operands, fp32 MFMA accumulate (v_mfma_f32_32x32x16_f16).  Weights [c_out][kh*kw*c_in]
@@ -158,10 +161,11 @@ typedef struct MetroConvDesc {
 int  metro_conv_f16(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                     const void* d_pro_scale, const void* d_pro_shift, const void* d_residual,
                     void* d_out, void* stream);
-/* fp32 activations, fp64 weights/bias/prologue, v_mfma_f64_16x16x4_f64 accumulate, fp32 out. */
-int  metro_conv_f64acc(const MetroConvDesc* d, const float* d_in, const double* d_w,
+/* fp32 or fp64 activations (in_dtype / out_dtype), fp64 weights/bias/prologue,
+ * v_mfma_f64_16x16x4_f64 accumulate, one rounding to out_dtype. */
+int  metro_conv_f64acc(const MetroConvDesc* d, const void* d_in, const double* d_w,
                        const double* d_bias, const double* d_pro_scale,
-                       const double* d_pro_shift, const float* d_residual, float* d_out,
+                       const double* d_pro_shift, const void* d_residual, void* d_out,
                        void* stream);
 
 /* fp32 NHWC [n,side,side,3] -> zero-bordered fp16 [n,side+6,side+8,4] (the stem's explicit
@@ -169,17 +173,17 @@ int  metro_conv_f64acc(const MetroConvDesc* d, const float* d_in, const double* 
 int  metro_prep_input_f16(const float* d_images, int32_t n, int32_t side, void* d_out, void* stream);
 
 /* 3x3 stride-2 max-pool over a ZERO-padded (1,1) input (reference resnet_utils.py:177-185).
- * dtype METRO_F16 or METRO_F32; c % 8 == 0 (f16) / c % 4 == 0 (f32). */
+ * dtype METRO_F16 / METRO_F32 / METRO_F64; c % 8 == 0 (f16), c % 4 == 0 (f32), c % 2 == 0 (f64). */
 int  metro_maxpool3x3s2_zeropad(const void* d_in, void* d_out, int32_t n, int32_t h_in,
                                 int32_t w_in, int32_t c, int32_t dtype, void* stream);
 
 /* Soft-argmax over the (H,W,D) volume per joint from fp32 NHWC logits [n,side,side,depth*J]
  * (channel = d*J + j), then mm decode, root-relative and joint permutation (reference
  * volumetric.py:227-235,288-306; tfu.py:466-499; tfu3d.py:23-25; main.py:127).
- * d_partials: scratch of metro_softargmax_scratch_bytes(); accumulate in fp32 (precise=0) or
- * fp64 (precise=1). */
+ * d_partials: scratch of metro_softargmax_scratch_bytes().  precise = 0: fp32 logits, fp32
+ * accumulators; 1: fp32 logits, fp64 accumulators; 2: fp64 logits, fp64 accumulators. */
 int64_t metro_softargmax_scratch_bytes(int32_t n, int32_t side, int32_t n_joints_head);
-int  metro_softargmax(const float* d_logits, int32_t n, const MetroSpec* spec, int32_t precise,
+int  metro_softargmax(const void* d_logits, int32_t n, const MetroSpec* spec, int32_t precise,
                       void* d_partials, float* d_poses_out, void* stream);
 
 const char* metro_last_error(void);

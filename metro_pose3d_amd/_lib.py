@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libmetro_hip.so')
 
 METRO_MAX_JOINTS = 64
-METRO_PREC_F16, METRO_PREC_F32 = 0, 1
+METRO_PREC_F16, METRO_PREC_F32, METRO_PREC_F64 = 0, 1, 2
 METRO_F16, METRO_F32, METRO_F64 = 0, 1, 2
 PARAM_CONV_W, PARAM_BIAS, PARAM_PRO_SCALE, PARAM_PRO_SHIFT = 0, 1, 2, 3
 LAYER_PREP, LAYER_CONV, LAYER_POOL, LAYER_SOFTARGMAX = 0, 1, 2, 3
@@ -49,7 +49,8 @@ class MetroConvDesc(C.Structure):
                 ('pad_top', C.c_int32), ('pad_left', C.c_int32),
                 ('has_prologue', C.c_int32), ('relu', C.c_int32), ('has_residual', C.c_int32),
                 ('res_h', C.c_int32), ('res_w', C.c_int32),
-                ('res_stride', C.c_int32), ('res_offset', C.c_int32), ('out_dtype', C.c_int32)]
+                ('res_stride', C.c_int32), ('res_offset', C.c_int32), ('out_dtype', C.c_int32),
+                ('in_dtype', C.c_int32)]
 
 
 # symbol -> (restype, argtypes); must list every function include/metro_hip.h declares

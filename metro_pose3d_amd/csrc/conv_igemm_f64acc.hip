@@ -1,6 +1,6 @@
-// Parity-mode implicit-GEMM convolution: fp32 NHWC activations in HBM, fp64 (BN-folded)
-// weights, every product and sum carried by v_mfma_f64_16x16x4_f64, ONE rounding to fp32 per
-// output element.  Same call sites as conv_igemm_f16.hip (reference resnet_v2.py:123-136,
+// Parity-mode implicit-GEMM convolution: fp32 or fp64 NHWC activations in HBM (template
+// TIn / TAct), fp64 (BN-folded) weights, every product and sum carried by
+// v_mfma_f64_16x16x4_f64, ONE rounding per output element (none when TAct = double).  Same call sites as conv_igemm_f16.hip (reference resnet_v2.py:123-136,
 // 219-220,233-236; resnet_utils.py:82-135), same descriptor, any c_in (the 3-channel stem runs
 // here directly with TF's explicit pad-3, resnet_utils.py:125-135).
 //
@@ -27,12 +27,12 @@ constexpr int P_LD = P_BK + 1;  // padded LDS row (doubles) -> conflict-free ds_
 constexpr int P_NT = 256;     // 4 waves, 2x2, each 32 pixels x 32 couts = 2x2 MFMA tiles
 }  // namespace
 
-template <bool PROLOGUE>
+template <bool PROLOGUE, typename TIn, typename TAct>
 __global__ __launch_bounds__(P_NT) void conv_igemm_f64acc_kernel(
-    ConvArgs a, const float* __restrict__ in, const double* __restrict__ w,
+    ConvArgs a, const TIn* __restrict__ in, const double* __restrict__ w,
     const double* __restrict__ bias, const double* __restrict__ pro_scale,
-    const double* __restrict__ pro_shift, const float* __restrict__ residual,
-    float* __restrict__ out) {
+    const double* __restrict__ pro_shift, const TAct* __restrict__ residual,
+    TAct* __restrict__ out) {
     __shared__ double xs[P_TM * P_LD];
     __shared__ double ws[P_TN * P_LD];
 
@@ -145,27 +145,39 @@ __global__ __launch_bounds__(P_NT) void conv_igemm_f64acc_kernel(
                 double v = acc[i][j][rr] + bias[co];
                 if (a.relu) v = fmax(v, 0.0);
                 if (residual != nullptr) v += (double)residual[res_pix * a.c_out + co];
-                out[(size_t)m * a.c_out + co] = (float)v;
+                out[(size_t)m * a.c_out + co] = (TAct)v;
             }
         }
     }
 }
 
-int launch_conv_f64acc(const MetroConvDesc& d, const float* in, const double* w, const double* bias,
-                       const double* ps, const double* pb, const float* res, float* out,
-                       hipStream_t stream) {
-    const ConvArgs a = make_conv_args(d);
+template <typename TIn, typename TAct>
+static int launch_t(const ConvArgs& a, bool pro, const void* in, const double* w, const double* bias,
+                    const double* ps, const double* pb, const void* res, void* out, hipStream_t stream) {
     const int tiles_c = (a.c_out + P_TN - 1) / P_TN;
     const int tiles_p = (a.m_total + P_TM - 1) / P_TM;
-    const float* r = d.has_residual ? res : nullptr;
-    if (d.has_prologue) {
-        hipLaunchKernelGGL(conv_igemm_f64acc_kernel<true>, dim3(tiles_c * tiles_p), dim3(P_NT), 0,
-                           stream, a, in, w, bias, ps, pb, r, out);
-    } else {
-        hipLaunchKernelGGL(conv_igemm_f64acc_kernel<false>, dim3(tiles_c * tiles_p), dim3(P_NT), 0,
-                           stream, a, in, w, bias, ps, pb, r, out);
-    }
+    if (pro)
+        hipLaunchKernelGGL((conv_igemm_f64acc_kernel<true, TIn, TAct>), dim3(tiles_c * tiles_p), dim3(P_NT), 0,
+                           stream, a, static_cast<const TIn*>(in), w, bias, ps, pb,
+                           static_cast<const TAct*>(res), static_cast<TAct*>(out));
+    else
+        hipLaunchKernelGGL((conv_igemm_f64acc_kernel<false, TIn, TAct>), dim3(tiles_c * tiles_p), dim3(P_NT), 0,
+                           stream, a, static_cast<const TIn*>(in), w, bias, ps, pb,
+                           static_cast<const TAct*>(res), static_cast<TAct*>(out));
     return launch_status("conv_igemm_f64acc");
+}
+
+int launch_conv_f64acc(const MetroConvDesc& d, const void* in, const double* w, const double* bias,
+                       const double* ps, const double* pb, const void* res, void* out,
+                       hipStream_t stream) {
+    const ConvArgs a = make_conv_args(d);
+    const void* r = d.has_residual ? res : nullptr;
+    const bool pro = d.has_prologue != 0;
+    if (d.in_dtype == METRO_F32 && d.out_dtype == METRO_F32) return launch_t<float, float>(a, pro, in, w, bias, ps, pb, r, out, stream);
+    if (d.in_dtype == METRO_F32 && d.out_dtype == METRO_F64) return launch_t<float, double>(a, pro, in, w, bias, ps, pb, r, out, stream);
+    if (d.in_dtype == METRO_F64 && d.out_dtype == METRO_F64) return launch_t<double, double>(a, pro, in, w, bias, ps, pb, r, out, stream);
+    set_error("conv_f64acc: unsupported in/out dtypes %d/%d", d.in_dtype, d.out_dtype);
+    return METRO_ERR_UNSUPPORTED;
 }
 
 }  // namespace metro

@@ -68,9 +68,9 @@ int validate_conv_desc(const MetroConvDesc* d);
 int launch_conv_f16(const MetroConvDesc& d, const void* in, const void* w, const float* bias,
                     const void* pro_scale, const void* pro_shift, const void* residual, void* out,
                     hipStream_t stream);
-int launch_conv_f64acc(const MetroConvDesc& d, const float* in, const double* w, const double* bias,
-                       const double* pro_scale, const double* pro_shift, const float* residual,
-                       float* out, hipStream_t stream);
+int launch_conv_f64acc(const MetroConvDesc& d, const void* in, const double* w, const double* bias,
+                       const double* pro_scale, const double* pro_shift, const void* residual,
+                       void* out, hipStream_t stream);
 int launch_prep_input_f16(const float* images, int n, int side, void* out, hipStream_t stream);
 int launch_maxpool(const void* in, void* out, int n, int h_in, int w_in, int c, int dtype,
                    hipStream_t stream);
@@ -84,7 +84,7 @@ struct SoftArgmaxArgs {
 };
 int softargmax_slabs(int n, int side);
 int64_t softargmax_scratch_bytes(int n, int side, int n_joints_head);
-int launch_softargmax(const float* logits, const SoftArgmaxArgs& a, bool precise, void* partials,
+int launch_softargmax(const void* logits, const SoftArgmaxArgs& a, int precise, void* partials,
                       float* poses_out, hipStream_t stream);
 SoftArgmaxArgs make_softargmax_args(const MetroSpec& spec, int n);
 

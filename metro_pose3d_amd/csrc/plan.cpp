@@ -75,6 +75,7 @@ struct MetroPlan {
     MetroSpec spec;
     int max_batch;
     bool fast;
+    int act_dtype;                       // MetroDType of activations in the workspace
     int act_bytes;                       // bytes per activation element in the workspace
     std::vector<MetroParamInfo> params;
     std::vector<Layer> layers;
@@ -124,7 +125,7 @@ struct Builder {
                   const std::string& prologue_bn, int in_slot, int out_slot, int res_slot,
                   int side_in, int c_in, int side_out, int c_out, int k, int stride, int dil,
                   int pad_beg, bool relu, int res_side, int res_stride, int res_offset,
-                  int out_dtype) {
+                  int out_dtype, int in_dtype) {
         Layer L;
         memset(&L, 0, sizeof(L));
         L.kind = LK_CONV;
@@ -142,6 +143,7 @@ struct Builder {
         cd.has_residual = res_slot != S_NONE;
         cd.res_h = cd.res_w = res_side; cd.res_stride = res_stride; cd.res_offset = res_offset;
         cd.out_dtype = out_dtype;
+        cd.in_dtype = in_dtype;
         const std::string conv_var = root + "/" + scope;
         const std::string bn_var = bn_fold.empty() ? "" : root + "/" + bn_fold;
         L.p_w = add_param(lname + "/W", METRO_PARAM_CONV_W, conv_var, bn_var, wdt, c_out, k, k, c_in, k, c_in);
@@ -153,7 +155,7 @@ struct Builder {
             L.p_shift = add_param(lname + "/pro_shift", METRO_PARAM_PRO_SHIFT, "", pv, wdt, c_in, 1, 1, 1, 1, 1);
         }
         L.in_slot = in_slot; L.out_slot = out_slot; L.res_slot = res_slot;
-        const int64_t out_es = out_dtype == METRO_F16 ? 2 : 4;
+        const int64_t out_es = out_dtype == METRO_F16 ? 2 : out_dtype == METRO_F32 ? 4 : 8;
         need(out_slot, (int64_t)side_out * side_out * c_out * out_es);
         fill_info(L, lname, (double)2.0 * side_out * side_out * c_out * k * k * c_in);
         p->layers.push_back(L);
@@ -186,8 +188,9 @@ int build_plan(MetroPlan* p) {
     const MetroSpec& sp = p->spec;
     Builder B{p, std::string("MainPart/resnet_v2_") + std::to_string(sp.arch)};
     const bool fast = p->fast;
-    const int adt = fast ? METRO_F16 : METRO_F32;
+    const int adt = p->act_dtype;
     const int aes = p->act_bytes;
+    const int ldt = sp.precision == METRO_PREC_F64 ? METRO_F64 : METRO_F32;   // logits dtype
     const int side = sp.proc_side;
     const int bw = sp.base_width;
 
@@ -216,7 +219,7 @@ int build_plan(MetroPlan* p) {
         cd.h_in = side + 6; cd.w_in = side + 8; cd.c_in = 32; cd.in_pix_stride = 4;
         cd.h_out = cd.w_out = s2; cd.c_out = bw;
         cd.kh = 7; cd.kw = 1; cd.stride = 2; cd.dilation = 1; cd.pad_top = cd.pad_left = 0;
-        cd.out_dtype = adt;
+        cd.out_dtype = adt; cd.in_dtype = METRO_F16;
         const std::string cv = B.root + "/conv1";
         S.p_w = B.add_param("conv1/W", METRO_PARAM_CONV_W, cv, "", METRO_F16, bw, 7, 7, 3, 8, 4);
         S.p_bias = B.add_param("conv1/bias", METRO_PARAM_BIAS, cv, "", METRO_F32, bw, 1, 1, 1, 1, 1);
@@ -227,7 +230,7 @@ int build_plan(MetroPlan* p) {
         p->layers.push_back(S);
     } else {
         B.add_conv("conv1", "conv1", "", "", S_IMAGES, S_STEM, S_NONE, side, 3, s2, bw, 7, 2, 1, 3,
-                   false, 0, 1, 0, adt);
+                   false, 0, 1, 0, adt, METRO_F32);
     }
     const int s4 = (s2 + 2 - 3) / 2 + 1;     // 64
     {
@@ -285,24 +288,24 @@ int build_plan(MetroPlan* p) {
             if (project) {
                 // conv1x1(shift(preact), stride s) + bias: input pixel = shift + s*ho
                 B.add_conv(un + "/shortcut", sc + "/shortcut", "", sc + "/preact", cur, S_SC, S_NONE,
-                           cur_side, cur_c, side_out, cout, 1, s, 1, -shift, false, 0, 1, 0, adt);
+                           cur_side, cur_c, side_out, cout, 1, s, 1, -shift, false, 0, 1, 0, adt, adt);
             }
             // conv1: 1x1 on preact, BN+ReLU folded (resnet_v2.py:127-128)
             B.add_conv(un + "/conv1", sc + "/conv1", sc + "/conv1/BatchNorm", sc + "/preact", cur, S_T1,
-                       S_NONE, cur_side, cur_c, cur_side, cb, 1, 1, 1, 0, true, 0, 1, 0, adt);
+                       S_NONE, cur_side, cur_c, cur_side, cb, 1, 1, 1, 0, true, 0, 1, 0, adt, adt);
             // conv2: conv2d_same 3x3 (resnet_utils.py:82-135)
             const int k_eff = 3 + 2 * (r - 1);
             const int pad_beg = (s == 1 || unit_centered) ? tf_same_pad_beg(cur_side, k_eff, s)
                                                           : (k_eff - 1) / 2;
             B.add_conv(un + "/conv2", sc + "/conv2", sc + "/conv2/BatchNorm", "", S_T1, S_T2, S_NONE,
-                       cur_side, cb, side_out, cb, 3, s, r, pad_beg, true, 0, 1, 0, adt);
+                       cur_side, cb, side_out, cb, 3, s, r, pad_beg, true, 0, 1, 0, adt, adt);
             // conv3 + bias + shortcut (resnet_v2.py:134-138)
             if (project)
                 B.add_conv(un + "/conv3", sc + "/conv3", "", "", S_T2, nxt, S_SC, side_out, cb, side_out,
-                           cout, 1, 1, 1, 0, false, side_out, 1, 0, adt);
+                           cout, 1, 1, 1, 0, false, side_out, 1, 0, adt, adt);
             else
                 B.add_conv(un + "/conv3", sc + "/conv3", "", "", S_T2, nxt, cur, side_out, cb, side_out,
-                           cout, 1, 1, 1, 0, false, cur_side, s, shift, adt);
+                           cout, 1, 1, 1, 0, false, cur_side, s, shift, adt, adt);
             cur = nxt; cur_side = side_out; cur_c = cout;
         }
     }
@@ -312,7 +315,7 @@ int build_plan(MetroPlan* p) {
     // ---- postnorm (prologue) + logits 1x1 (+bias), fp32 out (resnet_v2.py:229-236, architectures.py:34)
     const int c_head = sp.depth * sp.n_joints_head;
     B.add_conv("logits", "logits", "", "postnorm", cur, S_LOGITS, S_NONE, cur_side, cur_c, cur_side,
-               c_head, 1, 1, 1, 0, false, 0, 1, 0, METRO_F32);
+               c_head, 1, 1, 1, 0, false, 0, 1, 0, ldt, adt);
 
     // ---- soft-argmax + decode ---------------------------------------------------------------
     {
@@ -338,7 +341,7 @@ int build_plan(MetroPlan* p) {
     p->workspace_bytes = off;
     for (Layer& L : p->layers) {
         L.info.out_offset = L.out_slot >= 0 ? p->slot_offset[L.out_slot] : -1;
-        const int64_t es = L.cd.out_dtype == METRO_F16 ? 2 : 4;
+        const int64_t es = L.cd.out_dtype == METRO_F16 ? 2 : L.cd.out_dtype == METRO_F32 ? 4 : 8;
         L.info.out_bytes_per_image = (int64_t)L.cd.h_out * L.cd.w_out * L.cd.c_out * es;
     }
     return METRO_OK;
@@ -376,7 +379,7 @@ int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_
                 break;
             case LK_POOL:
                 st = launch_maxpool(slot_ptr(L.in_slot), slot_ptr(L.out_slot), n, L.cd.h_in, L.cd.w_in,
-                                    L.cd.c_in, p->fast ? METRO_F16 : METRO_F32, stream);
+                                    L.cd.c_in, p->act_dtype, stream);
                 break;
             case LK_CONV: {
                 MetroConvDesc cd = L.cd;
@@ -386,19 +389,18 @@ int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_
                                          prm(L.p_scale), prm(L.p_shift), slot_ptr(L.res_slot),
                                          slot_ptr(L.out_slot), stream);
                 else
-                    st = launch_conv_f64acc(cd, static_cast<const float*>(slot_ptr(L.in_slot)),
+                    st = launch_conv_f64acc(cd, slot_ptr(L.in_slot),
                                             static_cast<const double*>(prm(L.p_w)),
                                             static_cast<const double*>(prm(L.p_bias)),
                                             static_cast<const double*>(prm(L.p_scale)),
                                             static_cast<const double*>(prm(L.p_shift)),
-                                            static_cast<const float*>(slot_ptr(L.res_slot)),
-                                            static_cast<float*>(slot_ptr(L.out_slot)), stream);
+                                            slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream);
                 break;
             }
             case LK_SOFTARGMAX: {
                 if (poses == nullptr) { set_error("metro_forward: poses_out is NULL"); st = METRO_ERR_INVALID_ARG; break; }
                 const SoftArgmaxArgs a = make_softargmax_args(p->spec, n);
-                st = launch_softargmax(static_cast<const float*>(slot_ptr(L.in_slot)), a, !p->fast,
+                st = launch_softargmax(slot_ptr(L.in_slot), a, p->spec.precision,
                                        slot_ptr(S_PART), poses, stream);
                 break;
             }
@@ -438,7 +440,7 @@ int metro_plan_create(const MetroSpec* spec, int32_t max_batch, MetroPlan** out_
         METRO_CHECK_ARG(spec->permutation[i] >= 0 && spec->permutation[i] < spec->n_joints_head,
                         "permutation[%d] = %d outside the head's %d joints", i, spec->permutation[i], spec->n_joints_head);
     METRO_CHECK_ARG((spec->depth * spec->n_joints_head) % 4 == 0, "depth*n_joints_head must be a multiple of 4");
-    METRO_CHECK_ARG(spec->precision == METRO_PREC_F16 || spec->precision == METRO_PREC_F32, "unknown precision %d", spec->precision);
+    METRO_CHECK_ARG(spec->precision == METRO_PREC_F16 || spec->precision == METRO_PREC_F32 || spec->precision == METRO_PREC_F64, "unknown precision %d", spec->precision);
     METRO_CHECK_ARG(spec->base_width >= 8 && spec->base_width % 8 == 0, "base_width %d must be a positive multiple of 8", spec->base_width);
     METRO_CHECK_ARG(max_batch >= 1 && max_batch <= 4096, "max_batch %d out of range", max_batch);
     METRO_CHECK_ARG(spec->box_size_mm > 0.f, "box_size_mm must be positive");
@@ -447,7 +449,8 @@ int metro_plan_create(const MetroSpec* spec, int32_t max_batch, MetroPlan** out_
     p->spec = *spec;
     p->max_batch = max_batch;
     p->fast = spec->precision == METRO_PREC_F16;
-    p->act_bytes = p->fast ? 2 : 4;
+    p->act_dtype = p->fast ? METRO_F16 : spec->precision == METRO_PREC_F32 ? METRO_F32 : METRO_F64;
+    p->act_bytes = p->fast ? 2 : spec->precision == METRO_PREC_F32 ? 4 : 8;
     for (int s = 0; s < S_COUNT; ++s) { p->slot_bytes_per_image[s] = 0; p->slot_offset[s] = 0; }
     p->workspace_bytes = 0; p->param_bytes = 0; p->d_params = nullptr; p->flops_per_image = 0.0;
     const int st = build_plan(p);
@@ -506,6 +509,7 @@ int metro_conv_f16(const MetroConvDesc* d, const void* d_in, const void* d_w, co
     METRO_CHECK_ARG(d->c_in % 8 == 0 && d->in_pix_stride % 4 == 0, "conv_f16: c_in must be a multiple of 8 (got %d) and in_pix_stride of 4", d->c_in);
     METRO_CHECK_ARG(d->c_out % 4 == 0, "conv_f16: c_out must be a multiple of 4 (got %d)", d->c_out);
     METRO_CHECK_ARG(d->out_dtype == METRO_F16 || d->out_dtype == METRO_F32, "conv_f16: out_dtype must be F16 or F32");
+    METRO_CHECK_ARG(d->in_dtype == METRO_F16, "conv_f16: in_dtype must be F16");
     METRO_CHECK_ARG(d_in && d_w && d_bias && d_out, "conv_f16: NULL tensor pointer");
     METRO_CHECK_ARG(!d->has_prologue || (d_pro_scale && d_pro_shift), "conv_f16: prologue tensors missing");
     METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f16: residual tensor missing");
@@ -513,12 +517,14 @@ int metro_conv_f16(const MetroConvDesc* d, const void* d_in, const void* d_w, co
                            static_cast<hipStream_t>(stream));
 }
 
-int metro_conv_f64acc(const MetroConvDesc* d, const float* d_in, const double* d_w, const double* d_bias,
-                      const double* d_pro_scale, const double* d_pro_shift, const float* d_residual,
-                      float* d_out, void* stream) {
+int metro_conv_f64acc(const MetroConvDesc* d, const void* d_in, const double* d_w, const double* d_bias,
+                      const double* d_pro_scale, const double* d_pro_shift, const void* d_residual,
+                      void* d_out, void* stream) {
     int st = validate_conv_desc(d);
     if (st) return st;
-    METRO_CHECK_ARG(d->out_dtype == METRO_F32, "conv_f64acc: out_dtype must be F32");
+    METRO_CHECK_ARG((d->in_dtype == METRO_F32 || d->in_dtype == METRO_F64) && (d->out_dtype == METRO_F32 || d->out_dtype == METRO_F64) &&
+                        !(d->in_dtype == METRO_F64 && d->out_dtype == METRO_F32),
+                    "conv_f64acc: in/out dtypes must be F32/F32, F32/F64 or F64/F64");
     METRO_CHECK_ARG(d_in && d_w && d_bias && d_out, "conv_f64acc: NULL tensor pointer");
     METRO_CHECK_ARG(!d->has_prologue || (d_pro_scale && d_pro_shift), "conv_f64acc: prologue tensors missing");
     METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f64acc: residual tensor missing");
@@ -542,7 +548,7 @@ int64_t metro_softargmax_scratch_bytes(int32_t n, int32_t side, int32_t n_joints
     return softargmax_scratch_bytes(n, side, n_joints_head);
 }
 
-int metro_softargmax(const float* d_logits, int32_t n, const MetroSpec* spec, int32_t precise,
+int metro_softargmax(const void* d_logits, int32_t n, const MetroSpec* spec, int32_t precise,
                      void* d_partials, float* d_poses_out, void* stream) {
     METRO_CHECK_ARG(d_logits && spec && d_partials && d_poses_out && n > 0, "softargmax: bad argument");
     METRO_CHECK_ARG(spec->n_joints_head >= 1 && spec->n_joints_head <= METRO_MAX_JOINTS &&
@@ -550,7 +556,7 @@ int metro_softargmax(const float* d_logits, int32_t n, const MetroSpec* spec, in
                     "softargmax: joint counts out of range");
     METRO_CHECK_ARG(spec->proc_side / spec->stride >= 2, "softargmax: heat-map side must be >= 2");
     const SoftArgmaxArgs a = make_softargmax_args(*spec, n);
-    return launch_softargmax(d_logits, a, precise != 0, d_partials, d_poses_out, static_cast<hipStream_t>(stream));
+    return launch_softargmax(d_logits, a, precise, d_partials, d_poses_out, static_cast<hipStream_t>(stream));
 }
 
 const char* metro_last_error(void) { return metro::get_error(); }

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_zeropad_kernel(const VecT* _
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef double doublex2 __attribute__((ext_vector_type(2)));
 
 int launch_maxpool(const void* in, void* out, int n, int h_in, int w_in, int c, int dtype,
                    hipStream_t stream) {
@@ -110,6 +111,12 @@ int launch_maxpool(const void* in, void* out, int n, int h_in, int w_in, int c, 
         const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
         hipLaunchKernelGGL((maxpool3x3s2_zeropad_kernel<floatx4, 4>), dim3(blocks), dim3(256), 0, stream,
                            static_cast<const floatx4*>(in), static_cast<floatx4*>(out), n, h_in, w_in, c / 4);
+    } else if (dtype == METRO_F64) {
+        if (c % 2) { set_error("maxpool f64: channels %d not a multiple of 2", c); return METRO_ERR_INVALID_ARG; }
+        const long total = (long)n * h_out * w_out * (c / 2);
+        const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL((maxpool3x3s2_zeropad_kernel<doublex2, 2>), dim3(blocks), dim3(256), 0, stream,
+                           static_cast<const doublex2*>(in), static_cast<doublex2*>(out), n, h_in, w_in, c / 2);
     } else {
         set_error("maxpool: unsupported dtype %d", dtype);
         return METRO_ERR_INVALID_ARG;
@@ -154,9 +161,9 @@ __device__ __forceinline__ AccT acc_exp(AccT x);
 template <> __device__ __forceinline__ float acc_exp<float>(float x) { return __expf(x); }
 template <> __device__ __forceinline__ double acc_exp<double>(double x) { return exp(x); }
 
-template <typename AccT>
+template <typename AccT, typename LogitT>
 __global__ __launch_bounds__(SA_NT) void softargmax_partial_kernel(
-    const float* __restrict__ logits, AccT* __restrict__ partials, int side, int depth, int nj,
+    const LogitT* __restrict__ logits, AccT* __restrict__ partials, int side, int depth, int nj,
     int slabs) {
     extern __shared__ __attribute__((aligned(16))) char sa_smem[];
     AccT* red = reinterpret_cast<AccT*>(sa_smem);   // [ppb][C][4]: m, s, sx, sy
@@ -179,17 +186,17 @@ __global__ __launch_bounds__(SA_NT) void softargmax_partial_kernel(
     for (int e = 0; e < 4; ++e) { m[e] = (AccT)-INFINITY; s[e] = 0; sx[e] = 0; sy[e] = 0; }
 
     if (pp < ppb) {
-        const float* base = logits + (size_t)img * pixels * C + q * 4;
+        const LogitT* base = logits + (size_t)img * pixels * C + q * 4;
+        typedef LogitT logit4 __attribute__((ext_vector_type(4)));
         for (int p = p_begin + pp; p < p_end; p += ppb) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * C);
+            const logit4 v = *reinterpret_cast<const logit4*>(base + (size_t)p * C);
             const int h = p / side;
             const int wq = p - h * side;
             const AccT cx = (AccT)((float)wq * step_s);
             const AccT cy = (AccT)((float)h * step_s);
-            const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const AccT x = (AccT)vv[e];
+                const AccT x = (AccT)v[e];
                 if (x > m[e]) {                      // rare after the first few pixels
                     const AccT f = acc_exp<AccT>(m[e] - x);   // exp(-inf) = 0 on first touch
                     s[e] *= f; sx[e] *= f; sy[e] *= f;
@@ -285,15 +292,15 @@ SoftArgmaxArgs make_softargmax_args(const MetroSpec& spec, int n) {
     return a;
 }
 
-template <typename AccT>
-static int launch_softargmax_t(const float* logits, const SoftArgmaxArgs& a, void* partials,
+template <typename AccT, typename LogitT>
+static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void* partials,
                                float* poses, hipStream_t stream) {
     const int C = a.depth * a.n_joints_head;
     const int quads = C / 4;
     const int ppb = SA_NT / quads;
     const int slabs = softargmax_slabs(a.n, a.side);
     const size_t lds = (size_t)ppb * C * 4 * sizeof(AccT);
-    auto kern = softargmax_partial_kernel<AccT>;
+    auto kern = softargmax_partial_kernel<AccT, LogitT>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -303,7 +310,7 @@ static int launch_softargmax_t(const float* logits, const SoftArgmaxArgs& a, voi
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(slabs, a.n), dim3(SA_NT), lds, stream, logits,
+    hipLaunchKernelGGL(kern, dim3(slabs, a.n), dim3(SA_NT), lds, stream, static_cast<const LogitT*>(logits),
                        static_cast<AccT*>(partials), a.side, a.depth, a.n_joints_head, slabs);
     int st = launch_status("softargmax_partial");
     if (st) return st;
@@ -312,15 +319,18 @@ static int launch_softargmax_t(const float* logits, const SoftArgmaxArgs& a, voi
     return launch_status("softargmax_finalize");
 }
 
-int launch_softargmax(const float* logits, const SoftArgmaxArgs& a, bool precise, void* partials,
+int launch_softargmax(const void* logits, const SoftArgmaxArgs& a, int precise, void* partials,
                       float* poses_out, hipStream_t stream) {
     const int C = a.depth * a.n_joints_head;
     if (C % 4 || C / 4 > SA_NT || a.n_joints_head > METRO_MAX_JOINTS || a.n_joints_out > 64) {
         set_error("softargmax: unsupported head (depth %d, joints %d)", a.depth, a.n_joints_head);
         return METRO_ERR_UNSUPPORTED;
     }
-    return precise ? launch_softargmax_t<double>(logits, a, partials, poses_out, stream)
-                   : launch_softargmax_t<float>(logits, a, partials, poses_out, stream);
+    if (precise == 0) return launch_softargmax_t<float, float>(logits, a, partials, poses_out, stream);
+    if (precise == 1) return launch_softargmax_t<double, float>(logits, a, partials, poses_out, stream);
+    if (precise == 2) return launch_softargmax_t<double, double>(logits, a, partials, poses_out, stream);
+    set_error("softargmax: precise must be 0, 1 or 2 (got %d)", precise);
+    return METRO_ERR_INVALID_ARG;
 }
 
 }  // namespace metro

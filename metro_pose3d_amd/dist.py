@@ -56,5 +56,8 @@ def sharded_forward(forward_fn: Callable[[torch.Tensor], torch.Tensor], images: 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     b, e = shard_range(images.shape[0], rank, world)
-    local = forward_fn(images[b:e])
+    if e > b:
+        local = forward_fn(images[b:e])
+    else:                                   # more ranks than images: learn [J, 3] from one image
+        local = forward_fn(images[:1])[:0]
     return all_gather_poses(local, images.shape[0], group)

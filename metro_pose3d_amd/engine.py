@@ -17,7 +17,7 @@ from metro_pose3d_amd.spec import ModelSpec
 BN_EPS = 1e-5   # reference src/model/architectures.py:10
 
 _NP_DTYPE = {_lib.METRO_F16: np.float16, _lib.METRO_F32: np.float32, _lib.METRO_F64: np.float64}
-_PRECISIONS = {'f16': _lib.METRO_PREC_F16, 'f32': _lib.METRO_PREC_F32}
+_PRECISIONS = {'f16': _lib.METRO_PREC_F16, 'f32': _lib.METRO_PREC_F32, 'f64': _lib.METRO_PREC_F64}
 
 
 def _bn_scale_shift(params: Dict[str, np.ndarray], bn: str):
@@ -67,7 +67,7 @@ class Engine:
     def __init__(self, spec: ModelSpec, params: Optional[Dict[str, np.ndarray]],
                  precision: str = 'f16', max_batch: int = 64, device: Optional[torch.device] = None):
         if precision not in _PRECISIONS:
-            raise ValueError(f"precision must be 'f16' or 'f32', got {precision!r}")
+            raise ValueError(f"precision must be 'f16', 'f32' or 'f64', got {precision!r}")
         self.lib = _lib.load()
         self.spec = spec
         self.precision = precision
@@ -179,7 +179,8 @@ class Engine:
                                           C.c_void_p(stream), layer), 'metro_forward_upto')
         if li.kind == _lib.LAYER_SOFTARGMAX:
             return poses
-        dt = {_lib.METRO_F16: torch.float16, _lib.METRO_F32: torch.float32}[li.out_dtype]
+        dt = {_lib.METRO_F16: torch.float16, _lib.METRO_F32: torch.float32,
+              _lib.METRO_F64: torch.float64}[li.out_dtype]
         nbytes = li.out_bytes_per_image * n
         raw = self._ws[li.out_offset:li.out_offset + nbytes]
         return raw.view(dt).view(n, li.h_out, li.w_out, li.c_out).clone()

@@ -9,7 +9,7 @@ same CLI flag `--model-path`.  Differences that follow from not being TensorFlow
   * `model_path` is the container of modelfile.py (the `.pb` importer is SURVEY row f1).
 Input contract (inference.py:17-18, main.py:109-110): float32 NHWC [N,256,256,3], RGB in [0,1].
 The arithmetic mode defaults to fp16, the reference's default compute dtype (options.py:73);
-pass precision='f32' (or METRO_PRECISION=f32) for the parity mode.
+pass precision='f64' (or METRO_PRECISION=f64) for the parity mode (fp64 arithmetic inside).
 """
 from __future__ import annotations
 
@@ -99,7 +99,7 @@ def main(argv=None):
     parser.add_argument('--model-path', type=str, required=True)
     parser.add_argument('--image', type=str, default=None,
                         help='.npy file with a [256,256,3] float image in [0,1]; default: seeded noise')
-    parser.add_argument('--precision', type=str, default=None, choices=['f16', 'f32'])
+    parser.add_argument('--precision', type=str, default=None, choices=['f16', 'f32', 'f64'])
     parser.add_argument('--plot', type=str, default=None, help='write the stick-figure plot to this file')
     opts = parser.parse_args(argv)
     if opts.image:

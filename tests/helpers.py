@@ -16,7 +16,7 @@ def ptr(t):
 
 def conv_desc(n, h_in, c_in, h_out, c_out, k, stride=1, dil=1, pad=0, prologue=False, relu=False,
               residual=False, res_h=0, res_stride=1, res_offset=0, out_dtype=_lib.METRO_F16,
-              w_in=None, w_out=None, in_pix_stride=None, kh=None, kw=None):
+              w_in=None, w_out=None, in_pix_stride=None, kh=None, kw=None, in_dtype=None):
     d = _lib.MetroConvDesc()
     d.n = n
     d.h_in = h_in
@@ -38,6 +38,8 @@ def conv_desc(n, h_in, c_in, h_out, c_out, k, stride=1, dil=1, pad=0, prologue=F
     d.res_stride = res_stride
     d.res_offset = res_offset
     d.out_dtype = out_dtype
+    d.in_dtype = in_dtype if in_dtype is not None else (
+        _lib.METRO_F16 if out_dtype == _lib.METRO_F16 else out_dtype)
     return d
 
 
@@ -93,7 +95,9 @@ def run_conv_f16(lib, dev, d, x, w, bias, pro=None, res=None):
 
 
 def run_conv_f64acc(lib, dev, d, x, w, bias, pro=None, res=None):
-    tx = torch.from_numpy(np.ascontiguousarray(x.astype(np.float32))).to(dev)
+    np_in = np.float32 if d.in_dtype == _lib.METRO_F32 else np.float64
+    np_out = np.float32 if d.out_dtype == _lib.METRO_F32 else np.float64
+    tx = torch.from_numpy(np.ascontiguousarray(x.astype(np_in))).to(dev)
     tw = torch.from_numpy(np.ascontiguousarray(w.astype(np.float64))).to(dev)
     tb = torch.from_numpy(np.ascontiguousarray(bias.astype(np.float64))).to(dev)
     ts = tsh = tr = None
@@ -101,8 +105,9 @@ def run_conv_f64acc(lib, dev, d, x, w, bias, pro=None, res=None):
         ts = torch.from_numpy(pro[0].astype(np.float64)).to(dev)
         tsh = torch.from_numpy(pro[1].astype(np.float64)).to(dev)
     if res is not None:
-        tr = torch.from_numpy(np.ascontiguousarray(res.astype(np.float32))).to(dev)
-    out = torch.full((d.n, d.h_out, d.w_out, d.c_out), float('nan'), dtype=torch.float32, device=dev)
+        tr = torch.from_numpy(np.ascontiguousarray(res.astype(np_out))).to(dev)
+    out = torch.full((d.n, d.h_out, d.w_out, d.c_out), float('nan'),
+                     dtype=torch.float32 if np_out is np.float32 else torch.float64, device=dev)
     check(lib.metro_conv_f64acc(C.byref(d), ptr(tx), ptr(tw), ptr(tb), ptr(ts), ptr(tsh), ptr(tr),
                                 ptr(out), C.c_void_p(0)), 'metro_conv_f64acc')
     torch.cuda.synchronize()
@@ -112,8 +117,8 @@ def run_conv_f64acc(lib, dev, d, x, w, bias, pro=None, res=None):
 def run_softargmax(lib, dev, spec, logits, precise):
     """spec: metro_pose3d_amd.ModelSpec; logits numpy [n,S,S,D*J] fp32."""
     n = logits.shape[0]
-    cs = spec.to_c(_lib.METRO_PREC_F32 if precise else _lib.METRO_PREC_F16)
-    tl = torch.from_numpy(np.ascontiguousarray(logits.astype(np.float32))).to(dev)
+    cs = spec.to_c(int(precise))
+    tl = torch.from_numpy(np.ascontiguousarray(logits.astype(np.float64 if int(precise) == 2 else np.float32))).to(dev)
     sb = lib.metro_softargmax_scratch_bytes(n, spec.heatmap_side, spec.skeleton.n_head)
     scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
     out = torch.full((n, spec.skeleton.n_out, 3), float('nan'), dtype=torch.float32, device=dev)

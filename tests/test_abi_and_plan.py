@@ -1,0 +1,173 @@
+"""CPU-side checks of the boundary: the C ABI library loads and exports every symbol the header
+declares, ctypes struct layouts equal the compiler's, and the C++ planner agrees with the
+oracle's independent restatement of the reference's scheduler.  No compute, no GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from metro_pose3d_amd import ModelSpec, _lib, synth
+from metro_pose3d_amd.engine import Engine, pack_param
+from oracle.spec import OracleSpec, schedule
+from oracle.forward import tf_same_pads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'metro_hip.h')
+
+
+def _declared_functions():
+    text = re.sub(r'/\*.*?\*/', '', open(HEADER).read(), flags=re.S)
+    return sorted(set(re.findall(r'\b(metro_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/metro_hip.h but not exported'
+    assert sorted(_lib.SIGNATURES) == declared, 'bindings and header disagree'
+    assert lib.metro_abi_version() == 1
+
+
+def test_ctypes_struct_layout_matches_compiler(tmp_path):
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "metro_hip.h"\nint main(void){'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(MetroSpec), sizeof(MetroParamInfo), '
+                   'sizeof(MetroLayerInfo), sizeof(MetroConvDesc), offsetof(MetroParamInfo, offset), '
+                   'offsetof(MetroLayerInfo, flops_per_image), offsetof(MetroSpec, permutation));return 0;}')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    exp = [C.sizeof(_lib.MetroSpec), C.sizeof(_lib.MetroParamInfo), C.sizeof(_lib.MetroLayerInfo),
+           C.sizeof(_lib.MetroConvDesc), _lib.MetroParamInfo.offset.offset,
+           _lib.MetroLayerInfo.flops_per_image.offset, _lib.MetroSpec.permutation.offset]
+    assert got == exp
+
+
+# SURVEY.md 8(d) / BASELINE.md section 4: algorithmic GFLOP per crop
+FLOPS = {(50, 32, 'h36m'): 9.127, (50, 16, 'h36m'): 15.299, (50, 16, 'many19'): 15.316,
+         (101, 8, 'many19'): 88.733, (50, 4, 'h36m'): 194.656, (50, 8, 'h36m'): 49.877,
+         (101, 4, 'many19'): 350.08, (50, 16, 'merged'): 15.601, (101, 8, 'merged'): 89.873}
+
+
+@pytest.mark.parametrize('key', sorted(FLOPS), ids=lambda k: f'rn{k[0]}-s{k[1]}-{k[2]}')
+def test_plan_flops_match_published_accounting(key):
+    arch, stride, ds = key
+    for prec in ('f16', 'f64'):
+        eng = Engine(ModelSpec(arch, stride, ds), None, prec, max_batch=2)
+        assert abs(eng.flops_per_image / 1e9 - FLOPS[key]) < 5e-3 * max(1, FLOPS[key] / 100)
+
+
+@pytest.mark.parametrize('arch', [50, 101])
+@pytest.mark.parametrize('stride', [32, 16, 8, 4])
+@pytest.mark.parametrize('centered', [True, False])
+def test_planner_agrees_with_oracle_schedule(arch, stride, centered):
+    spec = ModelSpec(arch, stride, 'h36m', centered_stride=centered)
+    units = schedule(OracleSpec(arch=arch, stride=stride, centered_stride=centered))
+    layers = {li.name.decode(): li for li in Engine(spec, None, 'f16', max_batch=1).layer_infos()}
+    assert layers['conv1'].h_out == 128 and layers['pool1'].h_out == 64
+    for u in units:
+        c1, c2, c3 = (layers[f'{u.name}/conv{i}'] for i in (1, 2, 3))
+        assert (c1.c_in, c1.c_out, c1.h_in, c1.has_prologue, c1.relu) == (u.c_in, u.c_bott, u.side_in, 1, 1)
+        assert (c2.kh, c2.stride, c2.dilation, c2.h_in, c2.h_out, c2.c_out) == (3, u.stride, u.rate, u.side_in, u.side_out, u.c_bott)
+        k_eff = 3 + 2 * (u.rate - 1)
+        pad = tf_same_pads(u.side_in, k_eff, u.stride)[0] if (u.stride == 1 or u.centered) else (k_eff - 1) // 2
+        assert c2.pad_top == c2.pad_left == pad
+        shift = 1 if (u.centered and u.stride == 2) else 0
+        assert (c3.c_out, c3.has_residual, c3.relu, c3.has_prologue) == (u.c_out, 1, 0, 0)
+        if u.c_in == u.c_out:
+            assert f'{u.name}/shortcut' not in layers
+            assert (c3.res_stride, c3.res_offset) == (u.stride, shift)
+        else:
+            sc = layers[f'{u.name}/shortcut']
+            assert (sc.stride, sc.pad_top, sc.has_prologue, sc.c_out) == (u.stride, -shift, 1, u.c_out)
+            assert (c3.res_stride, c3.res_offset) == (1, 0)
+    lg = layers['logits']
+    assert (lg.h_out, lg.c_out, lg.has_prologue, lg.out_dtype) == (256 // stride, 136, 1, _lib.METRO_F32)
+
+
+def test_plan_rejects_bad_specs(lib):
+    good = ModelSpec(50, 16, 'h36m').to_c(_lib.METRO_PREC_F16)
+    plan = C.c_void_p()
+    for field, bad, needle in (('arch', 34, b'arch'), ('stride', 6, b'stride'), ('precision', 7, b'precision'),
+                               ('base_width', 12, b'base_width'), ('n_joints_head', 0, b'n_joints_head')):
+        cs = _lib.MetroSpec.from_buffer_copy(good)
+        setattr(cs, field, bad)
+        assert lib.metro_plan_create(C.byref(cs), 4, C.byref(plan)) == -1
+        assert needle in lib.metro_last_error()
+    assert lib.metro_plan_create(C.byref(good), 0, C.byref(plan)) == -1
+    with pytest.raises(ValueError):
+        ModelSpec(50, 12, 'h36m')
+    with pytest.raises(ValueError):
+        ModelSpec(50, 16, 'coco')
+
+
+def test_forward_without_bound_params_fails_loudly(lib):
+    eng = Engine(ModelSpec(50, 32, 'h36m', base_width=8), None, 'f16', max_batch=1)
+    st = lib.metro_forward(eng._plan, C.c_void_p(256), 1, C.c_void_p(256), C.c_void_p(256), None)
+    assert st == _lib.__dict__.get('METRO_ERR_STATE', -4) and b'not bound' in lib.metro_last_error()
+
+
+def test_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.MetroError, match='no CPU fallback'):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'metro_pose3d_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.cpp', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+    code = 'import sys; import metro_pose3d_amd, metro_pose3d_amd.engine, metro_pose3d_amd.inference, metro_pose3d_amd.dist; ' \
+           'assert not any(m == "oracle" or m.startswith("oracle.") for m in sys.modules)'
+    subprocess.check_call([sys.executable, '-c', code], cwd=ROOT)
+
+
+def test_param_packing_folds_batchnorm():
+    spec = ModelSpec(50, 16, 'h36m', base_width=8)
+    params = synth.make_params(50, spec.n_head_channels, 8, seed=1)
+    eng = Engine(spec, None, 'f64', max_batch=1)
+    infos = {pi.name.decode(): pi for pi in eng.param_infos()}
+    root = 'MainPart/resnet_v2_50/block1/unit_1/bottleneck_v2'
+    g, b, m, v = (params[f'{root}/conv1/BatchNorm/{k}'].astype(np.float64)
+                  for k in ('gamma', 'beta', 'moving_mean', 'moving_variance'))
+    scale = g / np.sqrt(v + 1e-5)
+    w = pack_param(infos['block1/unit_1/conv1/W'], params)
+    assert w.shape == (8, 1, 1, 8) and w.dtype == np.float64
+    ref = params[f'{root}/conv1/weights'].astype(np.float64)[0, 0].T * scale[:, None]
+    assert np.allclose(w[:, 0, 0, :], ref, rtol=0, atol=1e-15)
+    assert np.allclose(pack_param(infos['block1/unit_1/conv1/bias'], params), b - m * scale, atol=1e-15)
+    # conv3 has its own biases and no BN
+    assert np.array_equal(pack_param(infos['block1/unit_1/conv3/bias'], params),
+                          params[f'{root}/conv3/biases'].astype(np.float64))
+    # f16 plan: stem kernel padded 7x7x3 -> 7x8x4 with zeros
+    e16 = Engine(spec, None, 'f16', max_batch=1)
+    i16 = {pi.name.decode(): pi for pi in e16.param_infos()}
+    ws = pack_param(i16['conv1/W'], params)
+    assert ws.shape == (8, 7, 8, 4) and ws.dtype == np.float16
+    assert (ws[:, :, 7, :] == 0).all() and (ws[:, :, :, 3] == 0).all()
+    assert np.array_equal(ws[:, :, :7, :3], params['MainPart/resnet_v2_50/conv1/weights'].transpose(3, 0, 1, 2).astype(np.float16))
+    blob = e16.pack_params(params)
+    assert blob.dtype == np.uint8 and blob.size == e16.param_bytes
+
+
+def test_model_file_roundtrip(tmp_path):
+    from metro_pose3d_amd import load_model, save_model
+    spec = ModelSpec(101, 8, 'merged', base_width=8)
+    params = synth.make_params(101, spec.n_head_channels, 8)
+    path = str(tmp_path / 'm.npz')
+    save_model(path, spec, params)
+    spec2, params2 = load_model(path)
+    assert spec2 == spec and sorted(params2) == sorted(params)
+    assert all(np.array_equal(params[k], params2[k]) for k in params)
+    np.savez(str(tmp_path / 'junk.npz'), a=np.zeros(3))
+    with pytest.raises(ValueError):
+        load_model(str(tmp_path / 'junk.npz'))

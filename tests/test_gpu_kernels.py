@@ -55,7 +55,8 @@ def test_conv_f16(lib, cuda, case, variant):
         res = rng.standard_normal((n, h_out, h_out, c_out)).astype(np.float16)
     d = H.conv_desc(n, h_in, c_in, h_out, c_out, k, stride, dil, pad, prologue=pro is not None,
                     relu=variant == 'relu', residual=res is not None, res_h=h_out,
-                    out_dtype=_lib.METRO_F32 if variant == 'f32out' else _lib.METRO_F16)
+                    out_dtype=_lib.METRO_F32 if variant == 'f32out' else _lib.METRO_F16,
+                    in_dtype=_lib.METRO_F16)
     got = H.run_conv_f16(lib, cuda, d, x16, w16, b, pro, res).astype(np.float64)
     if pro is not None:
         # the kernel applies relu(x*s+b) with ONE fp16 rounding (v_pk_fma_f16): mirror it
@@ -87,7 +88,8 @@ def test_conv_f16_strided_residual(lib, cuda, res_stride, res_offset):
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 @pytest.mark.parametrize('variant', ['plain', 'relu_residual', 'prologue'])
-def test_conv_f64acc(lib, cuda, case, variant):
+@pytest.mark.parametrize('store', ['f32', 'f64'])
+def test_conv_f64acc(lib, cuda, case, variant, store):
     name, n, h_in, c_in, c_out, k, stride, dil, pad, h_out = case
     if variant == 'prologue' and (k != 1 or pad > 0):
         pytest.skip('prologue is defined for un-padded 1x1 convs only')
@@ -101,14 +103,17 @@ def test_conv_f64acc(lib, cuda, case, variant):
         res = rng.standard_normal((n, h_out, h_out, c_out)).astype(np.float32)
     d = H.conv_desc(n, h_in, c_in, h_out, c_out, k, stride, dil, pad, prologue=pro is not None,
                     relu=variant == 'relu_residual', residual=res is not None, res_h=h_out,
-                    out_dtype=_lib.METRO_F32)
+                    out_dtype=_lib.METRO_F32 if store == 'f32' else _lib.METRO_F64)
     got = H.run_conv_f64acc(lib, cuda, d, x, w, b.astype(np.float64), pro, res).astype(np.float64)
     ref = H.ref_conv_nhwc(x, w, b.astype(np.float64), stride, dil, pad, h_out, pro=pro,
                           relu=variant == 'relu_residual', res=res).numpy()
     # fp64 accumulation, one rounding to fp32: at most 1 ulp of the result (plus reordering ~1e-15)
     err = np.abs(got - ref)
-    ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
-    assert (err <= 0.5001 * ulp + 1e-12).all(), (err / ulp).max()
+    if store == 'f32':
+        ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+        assert (err <= 0.5001 * ulp + 1e-12).all(), (err / ulp).max()
+    else:
+        assert err.max() <= 1e-12 * max(np.abs(ref).max(), 1.0), err.max()
 
 
 def test_conv_f64acc_stem_3ch(lib, cuda):
@@ -144,7 +149,7 @@ def test_stem_f16_via_bordered_image(lib, cuda):
     packed = np.zeros((co, 7, 8, 4), np.float16)
     packed[:, :, :7, :3] = w_hwio.transpose(3, 0, 1, 2).astype(np.float16)
     d = H.conv_desc(n, side + 6, 32, side // 2, co, 0, stride=2, pad=0, w_in=side + 8, in_pix_stride=4,
-                    kh=7, kw=1)
+                    kh=7, kw=1, in_dtype=_lib.METRO_F16)
     got = H.run_conv_f16(lib, cuda, d, p, packed.reshape(co, 7, 1, 32), b).astype(np.float64)
     ref = conv2d_same(torch.from_numpy(x.astype(np.float16)).double().permute(0, 3, 1, 2),
                       torch.from_numpy(w_hwio.astype(np.float16)).double().permute(3, 2, 0, 1), 2, 1,
@@ -152,17 +157,17 @@ def test_stem_f16_via_bordered_image(lib, cuda):
     assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize('dtype', ['f16', 'f32'])
+@pytest.mark.parametrize('dtype', ['f16', 'f32', 'f64'])
 def test_maxpool_zeropad(lib, cuda, dtype):
     from oracle.forward import max_pool2d_same_zeropad
     rng = np.random.default_rng(9)
-    tdt = torch.float16 if dtype == 'f16' else torch.float32
+    tdt = {'f16': torch.float16, 'f32': torch.float32, 'f64': torch.float64}[dtype]
     x = torch.from_numpy(rng.standard_normal((3, 32, 32, 64)).astype(np.float32)).to(tdt)
     x[1] = -x[1].abs() - 0.5                       # KA7: all-negative image
     out = torch.full((3, 16, 16, 64), float('nan'), dtype=tdt, device=cuda)
     xd = x.to(cuda)
     check(lib.metro_maxpool3x3s2_zeropad(H.ptr(xd), H.ptr(out), 3, 32, 32, 64,
-                                         _lib.METRO_F16 if dtype == 'f16' else _lib.METRO_F32,
+                                         {'f16': _lib.METRO_F16, 'f32': _lib.METRO_F32, 'f64': _lib.METRO_F64}[dtype],
                                          C.c_void_p(0)), 'maxpool')
     torch.cuda.synchronize()
     ref = max_pool2d_same_zeropad(x.double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
@@ -177,7 +182,7 @@ SA_SPECS = [ModelSpec(50, 32, 'h36m'), ModelSpec(50, 16, 'h36m'), ModelSpec(50, 
 
 
 @pytest.mark.parametrize('spec', SA_SPECS, ids=lambda s: f'rn{s.arch}-s{s.stride}-{s.dataset}')
-@pytest.mark.parametrize('precise', [False, True])
+@pytest.mark.parametrize('precise', [0, 1, 2])
 def test_softargmax_random(lib, cuda, spec, precise):
     from oracle.forward import logits_to_output
     rng = np.random.default_rng(spec.stride)
@@ -204,7 +209,7 @@ def test_softargmax_known_answers(lib, cuda):
         pos[jj] = (w, h, d_)
         logits[0, h, w, d_ * j + jj] = 60.0                # channel = d*J + j (volumetric.py:231)
     logits[1] = 1.25                                        # uniform
-    for precise in (False, True):
+    for precise in (0, 1, 2):
         got = H.run_softargmax(lib, cuda, spec, logits, precise)
         head = np.array([[mm(pos[jj][0] / (s - 1)), mm(pos[jj][1] / (s - 1)), pos[jj][2] / (dd - 1) * 2200.0]
                          for jj in range(j)])
@@ -224,7 +229,7 @@ def test_softargmax_online_rescale_branch(lib, cuda):
     base = np.arange(s * s, dtype=np.float32).reshape(1, s, s, 1) * 0.05
     logits = np.broadcast_to(base, (1, s, s, c)).copy()
     logits += np.random.default_rng(0).standard_normal(logits.shape).astype(np.float32) * 0.01
-    for precise in (False, True):
+    for precise in (0, 1, 2):
         got = H.run_softargmax(lib, cuda, spec, logits, precise)
         ref = logits_to_output(H.oracle_spec(spec), logits).numpy()
         assert np.abs(got - ref).max() <= (1e-3 if precise else 5e-2)
