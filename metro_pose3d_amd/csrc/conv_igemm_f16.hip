@@ -18,6 +18,8 @@
 //   MFMAs of step k run.
 // * Epilogue: + bias, optional ReLU, optional residual add with the (strided, shifted) gather
 //   of the identity shortcut (resnet_v2.py:113-121, resnet_utils.py:76-79), one rounding.
+#include <cstdlib>
+
 #include "metro_common.h"
 
 namespace metro {
@@ -313,8 +315,20 @@ using Cfg128x64 = TileCfg<2, 2, 2, 1>;    // 128 cout x  64 pixels, wave tile 64
 using Cfg64x128 = TileCfg<1, 4, 2, 1>;    //  64 cout x 128 pixels, wave tile 64x32
 using Cfg64x64 = TileCfg<2, 2, 1, 1>;     //  64 cout x  64 pixels, wave tile 32x32
 
+// METRO_CONV_VARIANT=0 forces the first-generation register-staged kernel everywhere (A/B runs)
+static int conv_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("METRO_CONV_VARIANT");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
 int launch_conv_f16(const MetroConvDesc& d, const void* in_, const void* w_, const float* bias,
                     const void* ps_, const void* pb_, const void* res_, void* out, hipStream_t stream) {
+    if (conv_variant() != 0 && conv_f16_dma_supported(d))
+        return launch_conv_f16_dma(d, in_, w_, bias, ps_, pb_, res_, out, stream);
     const ConvArgs a = make_conv_args(d);
     const half_t* in = static_cast<const half_t*>(in_);
     const half_t* w = static_cast<const half_t*>(w_);

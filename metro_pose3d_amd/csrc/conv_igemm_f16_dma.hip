@@ -1,0 +1,413 @@
+// Second-generation fp16 implicit-GEMM convolution: LDS-DMA ring + coalesced epilogue.
+//
+// Same contraction, operand roles and swizzled LDS image as conv_igemm_f16.hip, but
+//   * operand tiles go global -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no
+//     ds_write pass): one wave-instruction fills 8 tile rows x 128 B.  The LDS image of an
+//     LDS-DMA is lane-linear, so the XOR chunk swizzle is applied to the per-lane SOURCE address;
+//   * TF zero padding, ragged tile edges and the c_in tail are served from a 16-byte zero page
+//     (a lane cannot be masked out of an LDS-DMA without leaving stale bytes in its slot);
+//   * a STAGES-deep ring keeps STAGES-1 K-steps in flight: each iteration waits with a COUNTED
+//     s_waitcnt vmcnt(N) for its own step only, one raw s_barrier per step orders both the landing
+//     of step k (RAW) and the reuse of the slot freed by step k-1 (WAR);
+//   * the pre-activation BatchNorm+ReLU (reference resnet_v2.py:119,229) is applied to the pixel
+//     fragment after its ds_read_b128 (4 v_pk_fma_f16 + 4 v_pk_max_f16), scale/shift in LDS;
+//   * the epilogue transposes the accumulators through the (now idle) ring: every lane then owns
+//     16 contiguous bytes of an NHWC row, so residual loads and output stores are full-line.
+//     conv+bias is rounded to fp16 before the shortcut add, exactly the reference's fp16 graph
+//     (BiasAdd output is fp16, then Add: resnet_v2.py:134-138 under tfu.py:426-440).
+#include "metro_common.h"
+
+namespace metro {
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4];   // zero-initialised
+
+template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int STAGES_>
+struct DmaCfg {
+    static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM = WM_, WN = WN_, STAGES = STAGES_;
+    static constexpr int BK = 64;
+    static constexpr int NW = WAVES_M * WAVES_N;
+    static constexpr int NT = 64 * NW;
+    static constexpr int TM = WAVES_M * WM * 32;          // output channels per block
+    static constexpr int TN = WAVES_N * WN * 32;          // pixels per block
+    static constexpr int WI = TM / (8 * NW);              // weight DMA instructions per wave per step
+    static constexpr int XI = TN / (8 * NW);              // pixel  DMA instructions per wave per step
+    static constexpr int LPS = WI + XI;
+    static constexpr int ROW_BYTES = BK * 2;
+    static constexpr int STAGE_BYTES = (TM + TN) * ROW_BYTES;
+    static constexpr int RING_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int OUT_ROW_BYTES = TM * 2 + 16;     // epilogue tile [TN][TM] fp16, padded rows
+    static constexpr int OUT_BYTES = TN * OUT_ROW_BYTES;
+    static constexpr int PRO_BYTES = 2 * 2048 * 2;        // scale + shift, c_in <= 2048
+    static_assert(TM % (8 * NW) == 0 && TN % (8 * NW) == 0, "tile/loader mismatch");
+    static_assert(OUT_BYTES <= RING_BYTES, "epilogue tile must fit in the ring");
+};
+
+__device__ __forceinline__ int swz8(int row) { return (row >> 1) & 7; }
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 bytes, lane l lands at lds_addr + 16*l.
+// Inline asm on purpose: hipcc tracks the builtin form as an LDS write that may alias every
+// later ds_read and drains it with s_waitcnt vmcnt(0), which serialises the ring.  The asm form
+// is invisible to its bookkeeping; completion is ordered by the counted waits below.
+// lds_addr must be wave-uniform (it goes through M0, saved/restored around the instruction).
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_addr)
+        : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+    return (unsigned)(size_t)(lds_void_t*)p;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <class Cfg, bool PROLOGUE>
+__global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
+    ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w,
+    const float* __restrict__ bias, const half_t* __restrict__ pro_scale,
+    const half_t* __restrict__ pro_shift, const half_t* __restrict__ residual,
+    void* __restrict__ out, int out_f32, int tiles_m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BK = Cfg::BK, STAGES = Cfg::STAGES, NW = Cfg::NW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / Cfg::WAVES_N;
+    const int wave_n = wave % Cfg::WAVES_N;
+
+    // XCD-aware (bijective) block -> tile map, as in conv_igemm_f16.hip
+    const int nblk = gridDim.x;
+    int lid;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, idx = b >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = lid / tiles_m;
+    const int tile_m = lid % tiles_m;
+    const int m0 = tile_n * Cfg::TN;
+    const int n0 = tile_m * Cfg::TM;
+
+    const int taps = a.kh * a.kw;
+    const int k_total = taps * a.c_in;
+    const int kc_steps = (a.c_in + BK - 1) / BK;
+    const int nk = taps * kc_steps;
+    const int hw_out = a.h_out * a.w_out;
+    const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page);
+    const unsigned smem_base = lds_offset_of(smem);
+
+    // ---- pre-activation BN parameters into LDS (behind the ring) --------------------------
+    half_t* pro_lds = reinterpret_cast<half_t*>(smem + Cfg::RING_BYTES);
+    if (PROLOGUE) {
+        const int cpad = kc_steps * BK;
+        for (int c = tid * 8; c < cpad; c += Cfg::NT * 8) {
+            uint4 sv = make_uint4(0, 0, 0, 0), bv = make_uint4(0, 0, 0, 0);
+            if (c < a.c_in) {
+                sv = *reinterpret_cast<const uint4*>(pro_scale + c);
+                bv = *reinterpret_cast<const uint4*>(pro_shift + c);
+            }
+            *reinterpret_cast<uint4*>(pro_lds + c) = sv;
+            *reinterpret_cast<uint4*>(pro_lds + 2048 + c) = bv;
+        }
+    }
+
+    // ---- per-lane DMA source coordinates ----------------------------------------------------
+    const int lrow = lane >> 3;     // row within an 8-row DMA group
+    const int lch = lane & 7;       // physical 16-byte chunk within the 128-byte row
+    const half_t* wsrc[Cfg::WI];
+    int wkoff[Cfg::WI];
+    bool wvalid[Cfg::WI];
+#pragma unroll
+    for (int i = 0; i < Cfg::WI; ++i) {
+        const int row = (i * NW + wave) * 8 + lrow;
+        const int co = n0 + row;
+        wvalid[i] = co < a.c_out;
+        wsrc[i] = w + (size_t)(wvalid[i] ? co : 0) * k_total;
+        wkoff[i] = (lch ^ swz8(row)) * 8;
+    }
+    int xh[Cfg::XI], xw[Cfg::XI], xn[Cfg::XI], xkoff[Cfg::XI];
+    bool xvalid[Cfg::XI];
+#pragma unroll
+    for (int i = 0; i < Cfg::XI; ++i) {
+        const int row = (i * NW + wave) * 8 + lrow;
+        const int m = m0 + row;
+        xvalid[i] = m < a.m_total;
+        const int mm = xvalid[i] ? m : 0;
+        const int img = mm / hw_out;
+        const int rem = mm - img * hw_out;
+        const int ho = rem / a.w_out;
+        const int wo = rem - ho * a.w_out;
+        xh[i] = ho * a.stride - a.pad_top;
+        xw[i] = wo * a.stride - a.pad_left;
+        xn[i] = img * a.h_in * a.w_in;
+        xkoff[i] = (lch ^ swz8(row)) * 8;
+    }
+
+    // issue state: (tap, c0) of the next step to issue, advanced incrementally
+    int is_tap = 0, is_c0 = 0, is_r = 0, is_s = 0;
+    auto issue_step = [&](int buf) {
+        const unsigned wl = __builtin_amdgcn_readfirstlane(smem_base + buf * Cfg::STAGE_BYTES +
+                                                           wave * 8 * Cfg::ROW_BYTES);
+        const unsigned xl = wl + Cfg::TM * Cfg::ROW_BYTES;
+        const int kbase = is_tap * a.c_in + is_c0;
+#pragma unroll
+        for (int i = 0; i < Cfg::WI; ++i) {
+            const int c = is_c0 + wkoff[i];
+            const half_t* src = (wvalid[i] && c < a.c_in) ? wsrc[i] + kbase + wkoff[i] : zero;
+            dma16(src, wl + i * NW * 8 * Cfg::ROW_BYTES);
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::XI; ++i) {
+            const int hi = xh[i] + is_r * a.dil;
+            const int wi = xw[i] + is_s * a.dil;
+            const int c = is_c0 + xkoff[i];
+            const bool ok = xvalid[i] && c < a.c_in && (unsigned)hi < (unsigned)a.h_in &&
+                            (unsigned)wi < (unsigned)a.w_in;
+            const half_t* src = ok ? in + (size_t)(xn[i] + hi * a.w_in + wi) * a.in_pix_stride + c : zero;
+            dma16(src, xl + i * NW * 8 * Cfg::ROW_BYTES);
+        }
+        is_c0 += BK;
+        if (is_c0 >= a.c_in) {
+            is_c0 = 0;
+            ++is_tap;
+            if (++is_s == a.kw) { is_s = 0; ++is_r; }
+        }
+    };
+
+    floatx16 acc[Cfg::WM][Cfg::WN];
+#pragma unroll
+    for (int i = 0; i < Cfg::WM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_half = lane >> 5;
+
+    auto compute_step = [&](int buf, int c0) {
+        const char* wl = smem + buf * Cfg::STAGE_BYTES;
+        const char* xl = wl + Cfg::TM * Cfg::ROW_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            half8_t af[Cfg::WM], bf[Cfg::WN];
+            const int chunk = kk * 2 + frag_half;
+#pragma unroll
+            for (int i = 0; i < Cfg::WM; ++i) {
+                const int row = (wave_m * Cfg::WM + i) * 32 + frag_row;
+                af[i] = *reinterpret_cast<const half8_t*>(wl + row * Cfg::ROW_BYTES + ((chunk ^ swz8(row)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < Cfg::WN; ++j) {
+                const int row = (wave_n * Cfg::WN + j) * 32 + frag_row;
+                bf[j] = *reinterpret_cast<const half8_t*>(xl + row * Cfg::ROW_BYTES + ((chunk ^ swz8(row)) << 4));
+            }
+            if (PROLOGUE) {
+                const half8_t sc = *reinterpret_cast<const half8_t*>(pro_lds + c0 + chunk * 8);
+                const half8_t sh = *reinterpret_cast<const half8_t*>(pro_lds + 2048 + c0 + chunk * 8);
+                const half8_t z = {};
+#pragma unroll
+                for (int j = 0; j < Cfg::WN; ++j) bf[j] = __builtin_elementwise_max(bf[j] * sc + sh, z);
+            }
+#pragma unroll
+            for (int i = 0; i < Cfg::WM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: STAGES-1 steps in flight -------------------------------------------------
+    if (PROLOGUE) __syncthreads();   // pro_lds written (also drains the ordinary loads above)
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue_step(s);
+    int cbuf = 0, ibuf = STAGES - 1, cc0 = 0;
+    for (int k = 0; k < nk; ++k) {
+        // steps still allowed in flight once step k has landed
+        const int ahead = nk - 1 - k;
+        if (STAGES >= 4 && ahead >= 2) wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS>();
+        else if (STAGES >= 3 && ahead >= 1) wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS>();
+        else wait_vm_and_barrier<0>();
+        if (k + STAGES - 1 < nk) issue_step(ibuf);
+        compute_step(cbuf, cc0);
+        cbuf = cbuf + 1 == STAGES ? 0 : cbuf + 1;
+        ibuf = ibuf + 1 == STAGES ? 0 : ibuf + 1;
+        cc0 += BK;
+        if (cc0 >= a.c_in) cc0 = 0;
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------
+    if (out_f32) {
+        // fp32 output (logits): direct stores, 16 bytes per lane
+#pragma unroll
+        for (int j = 0; j < Cfg::WN; ++j) {
+            const int m = m0 + (wave_n * Cfg::WN + j) * 32 + frag_row;
+            if (m >= a.m_total) continue;
+#pragma unroll
+            for (int i = 0; i < Cfg::WM; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = n0 + (wave_m * Cfg::WM + i) * 32 + 8 * q + 4 * frag_half;
+                    if (co >= a.c_out) continue;
+                    const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + co);
+                    floatx4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + bv[e];
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(out) + (size_t)m * a.c_out + co) = v;
+                }
+            }
+        }
+        return;
+    }
+
+    __syncthreads();   // every wave is done reading the ring
+    // 1) accumulators (+bias, ReLU) -> LDS tile [pixel][cout] fp16
+#pragma unroll
+    for (int i = 0; i < Cfg::WM; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = (wave_m * Cfg::WM + i) * 32 + 8 * q + 4 * frag_half;   // within the tile
+            const int co = n0 + col;
+            floatx4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (co < a.c_out) bv = *reinterpret_cast<const floatx4*>(bias + co);
+#pragma unroll
+            for (int j = 0; j < Cfg::WN; ++j) {
+                const int prow = (wave_n * Cfg::WN + j) * 32 + frag_row;
+                half4_t hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][4 * q + e] + bv[e];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    hv[e] = (half_t)v;
+                }
+                *reinterpret_cast<half4_t*>(smem + prow * Cfg::OUT_ROW_BYTES + col * 2) = hv;
+            }
+        }
+    }
+    __syncthreads();
+    // 2) row-wise: 16 bytes per lane, (+ residual), full-line stores
+    constexpr int CPRO = Cfg::TM / 8;                 // 16-byte chunks per tile row
+    half_t* outh = reinterpret_cast<half_t*>(out);
+    for (int idx = tid; idx < Cfg::TN * CPRO; idx += Cfg::NT) {
+        const int prow = idx / CPRO;
+        const int ch = idx - prow * CPRO;
+        const int m = m0 + prow;
+        const int co = n0 + ch * 8;
+        if (m >= a.m_total || co >= a.c_out) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16);
+        if (residual != nullptr) {
+            const int img = m / hw_out;
+            const int rem = m - img * hw_out;
+            const int ho = rem / a.w_out;
+            const int wo = rem - ho * a.w_out;
+            const size_t rp = (size_t)(img * a.res_h + ho * a.res_stride + a.res_offset) * a.res_w +
+                              (wo * a.res_stride + a.res_offset);
+            if (co + 8 <= a.c_out) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(residual + rp * a.c_out + co);
+                half2_t* x = reinterpret_cast<half2_t*>(&v);
+                const half2_t* r = reinterpret_cast<const half2_t*>(&rv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = x[e] + r[e];    // fp16 Add, like the reference graph
+            } else {
+                half8_t x = *reinterpret_cast<half8_t*>(&v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (co + e < a.c_out) x[e] = x[e] + residual[rp * a.c_out + co + e];
+                v = *reinterpret_cast<uint4*>(&x);
+            }
+        }
+        if (co + 8 <= a.c_out) {
+            *reinterpret_cast<uint4*>(outh + (size_t)m * a.c_out + co) = v;
+        } else {
+            const half8_t x = *reinterpret_cast<const half8_t*>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (co + e < a.c_out) outh[(size_t)m * a.c_out + co + e] = x[e];
+        }
+    }
+}
+
+template <class Cfg, bool PROLOGUE>
+static int launch_dma_cfg(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias,
+                          const half_t* ps, const half_t* pb, const half_t* res, void* out, int out_f32,
+                          hipStream_t stream) {
+    auto kern = conv_igemm_f16_dma_kernel<Cfg, PROLOGUE>;
+    constexpr int lds = Cfg::RING_BYTES + (PROLOGUE ? Cfg::PRO_BYTES : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(conv_igemm_f16_dma, %d B): %s", lds, hipGetErrorString(e));
+            return METRO_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const int tiles_m = (a.c_out + Cfg::TM - 1) / Cfg::TM;
+    const int tiles_n = (a.m_total + Cfg::TN - 1) / Cfg::TN;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::NT), lds, stream, a, in, w, bias, ps, pb,
+                       res, out, out_f32, tiles_m);
+    return launch_status("conv_igemm_f16_dma");
+}
+
+//                       WAVES_M WAVES_N WM WN STAGES      tile (cout x pixels), waves, ring
+using Dma128x256 = DmaCfg<2, 4, 2, 2, 3>;   // 128 x 256, 8 waves, 144 KiB
+using Dma128x128 = DmaCfg<2, 4, 2, 1, 4>;   // 128 x 128, 8 waves, 128 KiB
+using Dma64x128 = DmaCfg<1, 4, 2, 1, 3>;    //  64 x 128, 4 waves,  72 KiB (2 blocks / CU)
+using Dma64x64 = DmaCfg<1, 4, 2, 1, 3>;
+
+bool conv_f16_dma_supported(const MetroConvDesc& d) {
+    return d.in_pix_stride % 8 == 0 && d.c_in % 8 == 0 && d.c_in <= 2048 && d.c_out % 4 == 0 &&
+           (!d.has_residual || d.c_out % 8 == 0);
+}
+
+int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_, const float* bias,
+                        const void* ps_, const void* pb_, const void* res_, void* out, hipStream_t stream) {
+    const ConvArgs a = make_conv_args(d);
+    const half_t* in = static_cast<const half_t*>(in_);
+    const half_t* w = static_cast<const half_t*>(w_);
+    const half_t* ps = static_cast<const half_t*>(ps_);
+    const half_t* pb = static_cast<const half_t*>(pb_);
+    const half_t* res = d.has_residual ? static_cast<const half_t*>(res_) : nullptr;
+    const int out_f32 = d.out_dtype == METRO_F32;
+    const bool pro = d.has_prologue != 0;
+    const int tiles128 = (d.c_out + 127) / 128;
+#define METRO_DMA(CFG)                                                                         \
+    return pro ? launch_dma_cfg<CFG, true>(a, in, w, bias, ps, pb, res, out, out_f32, stream)  \
+               : launch_dma_cfg<CFG, false>(a, in, w, bias, ps, pb, res, out, out_f32, stream)
+    if (d.c_out <= 64) { METRO_DMA(Dma64x128); }
+    // 256-pixel tiles only when they still give every CU a block
+    const long blocks256 = (long)tiles128 * ((a.m_total + 255) / 256);
+    if (blocks256 >= 256) { METRO_DMA(Dma128x256); }
+    METRO_DMA(Dma128x128);
+#undef METRO_DMA
+}
+
+}  // namespace metro

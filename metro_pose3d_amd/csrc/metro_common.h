@@ -68,6 +68,12 @@ int validate_conv_desc(const MetroConvDesc* d);
 int launch_conv_f16(const MetroConvDesc& d, const void* in, const void* w, const float* bias,
                     const void* pro_scale, const void* pro_shift, const void* residual, void* out,
                     hipStream_t stream);
+// second-generation kernel (LDS-DMA ring, coalesced epilogue); falls back to launch_conv_f16's
+// register-staged kernel when the layer is not supported (the 4-channel stem image)
+bool conv_f16_dma_supported(const MetroConvDesc& d);
+int launch_conv_f16_dma(const MetroConvDesc& d, const void* in, const void* w, const float* bias,
+                        const void* pro_scale, const void* pro_shift, const void* residual, void* out,
+                        hipStream_t stream);
 int launch_conv_f64acc(const MetroConvDesc& d, const void* in, const double* w, const double* bias,
                        const double* pro_scale, const double* pro_shift, const void* residual,
                        void* out, hipStream_t stream);
