@@ -15,6 +15,8 @@
 //     16 contiguous bytes of an NHWC row, so residual loads and output stores are full-line.
 //     conv+bias is rounded to fp16 before the shortcut add, exactly the reference's fp16 graph
 //     (BiasAdd output is fp16, then Add: resnet_v2.py:134-138 under tfu.py:426-440).
+#include <cstdlib>
+
 #include "metro_common.h"
 
 namespace metro {
@@ -28,28 +30,34 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4];   // zero-initialised
 
-template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int STAGES_>
+template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int STAGES_, int BK_ = 64>
 struct DmaCfg {
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM = WM_, WN = WN_, STAGES = STAGES_;
-    static constexpr int BK = 64;
+    static constexpr int BK = BK_;                        // K elements per step: 64 or 32
+    static constexpr int CPR = BK / 8;                    // 16-byte chunks per tile row
+    static constexpr int RPI = 64 / CPR;                  // tile rows filled by one DMA wave-instruction
     static constexpr int NW = WAVES_M * WAVES_N;
     static constexpr int NT = 64 * NW;
     static constexpr int TM = WAVES_M * WM * 32;          // output channels per block
     static constexpr int TN = WAVES_N * WN * 32;          // pixels per block
-    static constexpr int WI = TM / (8 * NW);              // weight DMA instructions per wave per step
-    static constexpr int XI = TN / (8 * NW);              // pixel  DMA instructions per wave per step
+    static constexpr int WI = TM / (RPI * NW);            // weight DMA instructions per wave per step
+    static constexpr int XI = TN / (RPI * NW);            // pixel  DMA instructions per wave per step
     static constexpr int LPS = WI + XI;
     static constexpr int ROW_BYTES = BK * 2;
     static constexpr int STAGE_BYTES = (TM + TN) * ROW_BYTES;
     static constexpr int RING_BYTES = STAGES * STAGE_BYTES;
     static constexpr int OUT_ROW_BYTES = TM * 2 + 16;     // epilogue tile [TN][TM] fp16, padded rows
     static constexpr int OUT_BYTES = TN * OUT_ROW_BYTES;
+    static constexpr int MAIN_BYTES = RING_BYTES > OUT_BYTES ? RING_BYTES : OUT_BYTES;
     static constexpr int PRO_BYTES = 2 * 2048 * 2;        // scale + shift, c_in <= 2048
-    static_assert(TM % (8 * NW) == 0 && TN % (8 * NW) == 0, "tile/loader mismatch");
-    static_assert(OUT_BYTES <= RING_BYTES, "epilogue tile must fit in the ring");
+    static_assert(TM % (RPI * NW) == 0 && TN % (RPI * NW) == 0, "tile/loader mismatch");
+    static_assert(BK == 64 || BK == 32, "BK must be 32 or 64");
 };
 
-__device__ __forceinline__ int swz8(int row) { return (row >> 1) & 7; }
+// chunk swizzle so that ds_read_b128 of 32 rows x one chunk hits 16 distinct 16-byte slots per
+// 16-lane group: BK=64 (128-byte rows, 2 per bank row): (row>>1)&7; BK=32 (64-byte rows): (row>>2)&3
+template <int BK>
+__device__ __forceinline__ int swzk(int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     const unsigned smem_base = lds_offset_of(smem);
 
     // ---- pre-activation BN parameters into LDS (behind the ring) --------------------------
-    half_t* pro_lds = reinterpret_cast<half_t*>(smem + Cfg::RING_BYTES);
+    half_t* pro_lds = reinterpret_cast<half_t*>(smem + Cfg::MAIN_BYTES);
     if (PROLOGUE) {
         const int cpad = kc_steps * BK;
         for (int c = tid * 8; c < cpad; c += Cfg::NT * 8) {
@@ -134,24 +142,25 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     }
 
     // ---- per-lane DMA source coordinates ----------------------------------------------------
-    const int lrow = lane >> 3;     // row within an 8-row DMA group
-    const int lch = lane & 7;       // physical 16-byte chunk within the 128-byte row
+    constexpr int CPR = Cfg::CPR, RPI = Cfg::RPI;
+    const int lrow = lane / CPR;    // row within the RPI-row group one DMA instruction fills
+    const int lch = lane % CPR;     // physical 16-byte chunk within the row
     const half_t* wsrc[Cfg::WI];
     int wkoff[Cfg::WI];
     bool wvalid[Cfg::WI];
 #pragma unroll
     for (int i = 0; i < Cfg::WI; ++i) {
-        const int row = (i * NW + wave) * 8 + lrow;
+        const int row = (i * NW + wave) * RPI + lrow;
         const int co = n0 + row;
         wvalid[i] = co < a.c_out;
         wsrc[i] = w + (size_t)(wvalid[i] ? co : 0) * k_total;
-        wkoff[i] = (lch ^ swz8(row)) * 8;
+        wkoff[i] = (lch ^ swzk<BK>(row)) * 8;
     }
     int xh[Cfg::XI], xw[Cfg::XI], xn[Cfg::XI], xkoff[Cfg::XI];
     bool xvalid[Cfg::XI];
 #pragma unroll
     for (int i = 0; i < Cfg::XI; ++i) {
-        const int row = (i * NW + wave) * 8 + lrow;
+        const int row = (i * NW + wave) * RPI + lrow;
         const int m = m0 + row;
         xvalid[i] = m < a.m_total;
         const int mm = xvalid[i] ? m : 0;
@@ -162,38 +171,54 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
         xh[i] = ho * a.stride - a.pad_top;
         xw[i] = wo * a.stride - a.pad_left;
         xn[i] = img * a.h_in * a.w_in;
-        xkoff[i] = (lch ^ swz8(row)) * 8;
+        xkoff[i] = (lch ^ swzk<BK>(row)) * 8;
     }
 
     // issue state: (tap, c0) of the next step to issue, advanced incrementally
     int is_tap = 0, is_c0 = 0, is_r = 0, is_s = 0;
-    auto issue_step = [&](int buf) {
-        const unsigned wl = __builtin_amdgcn_readfirstlane(smem_base + buf * Cfg::STAGE_BYTES +
-                                                           wave * 8 * Cfg::ROW_BYTES);
-        const unsigned xl = wl + Cfg::TM * Cfg::ROW_BYTES;
-        const int kbase = is_tap * a.c_in + is_c0;
+    // One K-step's DMA is issued in SLICES parts so it can be interleaved with the MFMA groups of
+    // the step being computed (a burst right after the barrier leaves the L2 path idle later).
+    constexpr int SLICES = BK / 16;
+    unsigned is_wl = 0, is_xl = 0;
+    int is_kbase = 0;
+    auto issue_begin = [&](int buf) {
+        is_wl = __builtin_amdgcn_readfirstlane(smem_base + buf * Cfg::STAGE_BYTES + wave * RPI * Cfg::ROW_BYTES);
+        is_xl = is_wl + Cfg::TM * Cfg::ROW_BYTES;
+        is_kbase = is_tap * a.c_in + is_c0;
+    };
+    auto issue_part = [&](int part) {
 #pragma unroll
         for (int i = 0; i < Cfg::WI; ++i) {
+            if ((i % SLICES) != part) continue;
             const int c = is_c0 + wkoff[i];
-            const half_t* src = (wvalid[i] && c < a.c_in) ? wsrc[i] + kbase + wkoff[i] : zero;
-            dma16(src, wl + i * NW * 8 * Cfg::ROW_BYTES);
+            const half_t* src = (wvalid[i] && c < a.c_in) ? wsrc[i] + is_kbase + wkoff[i] : zero;
+            dma16(src, is_wl + i * NW * RPI * Cfg::ROW_BYTES);
         }
 #pragma unroll
         for (int i = 0; i < Cfg::XI; ++i) {
+            if (((i + Cfg::WI) % SLICES) != part) continue;
             const int hi = xh[i] + is_r * a.dil;
             const int wi = xw[i] + is_s * a.dil;
             const int c = is_c0 + xkoff[i];
             const bool ok = xvalid[i] && c < a.c_in && (unsigned)hi < (unsigned)a.h_in &&
                             (unsigned)wi < (unsigned)a.w_in;
             const half_t* src = ok ? in + (size_t)(xn[i] + hi * a.w_in + wi) * a.in_pix_stride + c : zero;
-            dma16(src, xl + i * NW * 8 * Cfg::ROW_BYTES);
+            dma16(src, is_xl + i * NW * RPI * Cfg::ROW_BYTES);
         }
+    };
+    auto issue_end = [&]() {
         is_c0 += BK;
         if (is_c0 >= a.c_in) {
             is_c0 = 0;
             ++is_tap;
             if (++is_s == a.kw) { is_s = 0; ++is_r; }
         }
+    };
+    auto issue_step = [&](int buf) {
+        issue_begin(buf);
+#pragma unroll
+        for (int p = 0; p < SLICES; ++p) issue_part(p);
+        issue_end();
     };
 
     floatx16 acc[Cfg::WM][Cfg::WN];
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     const int frag_row = lane & 31;
     const int frag_half = lane >> 5;
 
-    auto compute_step = [&](int buf, int c0) {
+    auto compute_step = [&](int buf, int c0, bool with_issue) {
         const char* wl = smem + buf * Cfg::STAGE_BYTES;
         const char* xl = wl + Cfg::TM * Cfg::ROW_BYTES;
 #pragma unroll
@@ -217,12 +242,12 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
 #pragma unroll
             for (int i = 0; i < Cfg::WM; ++i) {
                 const int row = (wave_m * Cfg::WM + i) * 32 + frag_row;
-                af[i] = *reinterpret_cast<const half8_t*>(wl + row * Cfg::ROW_BYTES + ((chunk ^ swz8(row)) << 4));
+                af[i] = *reinterpret_cast<const half8_t*>(wl + row * Cfg::ROW_BYTES + ((chunk ^ swzk<BK>(row)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < Cfg::WN; ++j) {
                 const int row = (wave_n * Cfg::WN + j) * 32 + frag_row;
-                bf[j] = *reinterpret_cast<const half8_t*>(xl + row * Cfg::ROW_BYTES + ((chunk ^ swz8(row)) << 4));
+                bf[j] = *reinterpret_cast<const half8_t*>(xl + row * Cfg::ROW_BYTES + ((chunk ^ swzk<BK>(row)) << 4));
             }
             if (PROLOGUE) {
                 const half8_t sc = *reinterpret_cast<const half8_t*>(pro_lds + c0 + chunk * 8);
@@ -236,27 +261,43 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
 #pragma unroll
                 for (int j = 0; j < Cfg::WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            if (with_issue) issue_part(kk);
         }
     };
 
     // ---- main loop: STAGES-1 steps in flight -------------------------------------------------
     if (PROLOGUE) __syncthreads();   // pro_lds written (also drains the ordinary loads above)
+    if constexpr (STAGES == 1) {
+        // single slot (short-K layers: small LDS footprint -> several blocks per CU overlap instead)
+        int cc0 = 0;
+        for (int k = 0; k < nk; ++k) {
+            if (k > 0) wait_vm_and_barrier<0>();      // WAR: everyone is done reading the slot
+            issue_step(0);
+            wait_vm_and_barrier<0>();                 // RAW: the step has landed for every wave
+            compute_step(0, cc0, false);
+            cc0 += BK;
+            if (cc0 >= a.c_in) cc0 = 0;
+        }
+    } else {
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) issue_step(s);
-    int cbuf = 0, ibuf = STAGES - 1, cc0 = 0;
-    for (int k = 0; k < nk; ++k) {
-        // steps still allowed in flight once step k has landed
-        const int ahead = nk - 1 - k;
-        if (STAGES >= 4 && ahead >= 2) wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS>();
-        else if (STAGES >= 3 && ahead >= 1) wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS>();
-        else wait_vm_and_barrier<0>();
-        if (k + STAGES - 1 < nk) issue_step(ibuf);
-        compute_step(cbuf, cc0);
-        cbuf = cbuf + 1 == STAGES ? 0 : cbuf + 1;
-        ibuf = ibuf + 1 == STAGES ? 0 : ibuf + 1;
-        cc0 += BK;
-        if (cc0 >= a.c_in) cc0 = 0;
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nk) issue_step(s);
+        int cbuf = 0, ibuf = STAGES - 1, cc0 = 0;
+        for (int k = 0; k < nk; ++k) {
+            // steps still allowed in flight once step k has landed
+            const int ahead = nk - 1 - k;
+            if (STAGES >= 4 && ahead >= 2) wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS>();
+            else if (STAGES >= 3 && ahead >= 1) wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS>();
+            else wait_vm_and_barrier<0>();
+            const bool more = k + STAGES - 1 < nk;
+            if (more) issue_begin(ibuf);
+            compute_step(cbuf, cc0, more);
+            if (more) issue_end();
+            cbuf = cbuf + 1 == STAGES ? 0 : cbuf + 1;
+            ibuf = ibuf + 1 == STAGES ? 0 : ibuf + 1;
+            cc0 += BK;
+            if (cc0 >= a.c_in) cc0 = 0;
+        }
     }
 
     // ---- epilogue -----------------------------------------------------------------------
@@ -354,12 +395,17 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     }
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 template <class Cfg, bool PROLOGUE>
 static int launch_dma_cfg(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias,
                           const half_t* ps, const half_t* pb, const half_t* res, void* out, int out_f32,
                           hipStream_t stream) {
     auto kern = conv_igemm_f16_dma_kernel<Cfg, PROLOGUE>;
-    constexpr int lds = Cfg::RING_BYTES + (PROLOGUE ? Cfg::PRO_BYTES : 0);
+    constexpr int lds = Cfg::MAIN_BYTES + (PROLOGUE ? Cfg::PRO_BYTES : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -377,15 +423,19 @@ static int launch_dma_cfg(const ConvArgs& a, const half_t* in, const half_t* w, 
     return launch_status("conv_igemm_f16_dma");
 }
 
-//                       WAVES_M WAVES_N WM WN STAGES      tile (cout x pixels), waves, ring
-using Dma128x256 = DmaCfg<2, 4, 2, 2, 3>;   // 128 x 256, 8 waves, 144 KiB
-using Dma128x128 = DmaCfg<2, 4, 2, 1, 4>;   // 128 x 128, 8 waves, 128 KiB
-using Dma64x128 = DmaCfg<1, 4, 2, 1, 3>;    //  64 x 128, 4 waves,  72 KiB (2 blocks / CU)
-using Dma64x64 = DmaCfg<1, 4, 2, 1, 3>;
+//                        WAVES_M WAVES_N WM WN STAGES BK   tile (cout x pixels), waves, LDS
+using Dma128x256s3 = DmaCfg<2, 4, 2, 2, 3>;        // 128 x 256, 8 waves, 144 KiB: deep-K, >= 256 tiles
+using Dma128x128s4 = DmaCfg<2, 4, 2, 1, 4>;        // 128 x 128, 8 waves, 128 KiB: deep-K, few tiles
+using Dma128x128s2 = DmaCfg<2, 4, 2, 1, 2>;        // 128 x 128, 8 waves,  64 KiB: 2 blocks / CU
+using Dma128x128s1 = DmaCfg<2, 4, 2, 1, 1>;        // 128 x 128, 8 waves,  34 KiB: 3 blocks / CU (K <= 64)
+using Dma64x128s3 = DmaCfg<1, 4, 2, 1, 3>;         //  64 x 128, 4 waves,  72 KiB
+using Dma64x128s1 = DmaCfg<1, 4, 2, 1, 1>;         //  64 x 128, 4 waves,  24 KiB
+using Dma64x128s3k32 = DmaCfg<1, 4, 2, 1, 3, 32>;  //  64 x 128, 4 waves, BK 32 (the stem's 32-wide taps)
 
 bool conv_f16_dma_supported(const MetroConvDesc& d) {
-    return d.in_pix_stride % 8 == 0 && d.c_in % 8 == 0 && d.c_in <= 2048 && d.c_out % 4 == 0 &&
-           (!d.has_residual || d.c_out % 8 == 0);
+    // in_pix_stride % 4: the 4-channel bordered stem image gives 8-byte-aligned 16-byte sources
+    return d.in_pix_stride % 4 == 0 && d.c_in % 8 == 0 && d.c_in <= 2048 && d.c_out % 4 == 0 &&
+           (!d.has_residual || d.c_out % 8 == 0) && (d.in_pix_stride % 8 == 0 || !d.has_prologue);
 }
 
 int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_, const float* bias,
@@ -399,14 +449,26 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
     const int out_f32 = d.out_dtype == METRO_F32;
     const bool pro = d.has_prologue != 0;
     const int tiles128 = (d.c_out + 127) / 128;
+    // tuning knobs (A/B runs): K-steps up to which the 1-stage / 2-stage 128x128 configs are used
+    static const int nk_s1 = env_int("METRO_NK_S1", 1);
+    static const int nk_s2 = env_int("METRO_NK_S2", 8);
 #define METRO_DMA(CFG)                                                                         \
     return pro ? launch_dma_cfg<CFG, true>(a, in, w, bias, ps, pb, res, out, out_f32, stream)  \
                : launch_dma_cfg<CFG, false>(a, in, w, bias, ps, pb, res, out, out_f32, stream)
-    if (d.c_out <= 64) { METRO_DMA(Dma64x128); }
+    if (d.c_in <= 32 && !pro) {
+        return launch_dma_cfg<Dma64x128s3k32, false>(a, in, w, bias, ps, pb, res, out, out_f32, stream);
+    }
+    const int nk = d.kh * d.kw * ((d.c_in + 63) / 64);
+    if (d.c_out <= 64) {
+        if (nk <= nk_s1) { METRO_DMA(Dma64x128s1); }
+        METRO_DMA(Dma64x128s3);
+    }
+    if (nk <= nk_s1) { METRO_DMA(Dma128x128s1); }
+    if (nk <= nk_s2) { METRO_DMA(Dma128x128s2); }
     // 256-pixel tiles only when they still give every CU a block
     const long blocks256 = (long)tiles128 * ((a.m_total + 255) / 256);
-    if (blocks256 >= 256) { METRO_DMA(Dma128x256); }
-    METRO_DMA(Dma128x128);
+    if (blocks256 >= 256) { METRO_DMA(Dma128x256s3); }
+    METRO_DMA(Dma128x128s4);
 #undef METRO_DMA
 }
 
