@@ -1,0 +1,348 @@
+// 3x3 stride-1 (dilated) convolution with TAP REUSE: the activation slab of a pixel tile is staged
+// in LDS once per 64-channel chunk and all 9 taps are served from it.
+//
+// The generic implicit GEMM (conv_igemm_f16_dma.hip) re-fetches the 256-pixel activation tile for
+// every tap, so a 3x3 layer moves 9x its activations from L2 into LDS; PMC showed those layers
+// bound by L2->LDS delivery (~9 TB/s of a ~16 TB/s LDS-DMA ceiling), not by MFMA.  Here:
+//   * a tile is 256 CONSECUTIVE pixels in (n,h,w) order (whole rows / whole images: consecutive
+//     in NHWC memory too).  Its slab is the flattened pixel range [m0 - halo, m0 + 256 + halo),
+//     halo = dil*W + dil: one contiguous range -> plain row-by-row LDS-DMA, 1/9 of the traffic;
+//   * tap (dr,ds) of tile pixel t reads slab row halo + t + (dr*W + ds)*dil, or a ZERO row when the
+//     tap leaves the image (TF SAME zero padding, reference resnet_utils.py:120-123); the per-lane
+//     row offsets of all 9 taps are computed once;
+//   * weights stream per (chunk, tap) step through a 3-deep LDS-DMA ring; the next chunk's slab is
+//     issued during the tap-0 step into the other slab buffer.  One raw s_barrier per step; waits
+//     are counted (s_waitcnt vmcnt(N)) over the merged in-order DMA stream.
+// Covers the reference's conv2 call sites with stride 1: resnet_v2.py:130-132 via
+// resnet_utils.conv2d_same (SAME padding, rate r).  Post-conv BN+ReLU folded (bias + ReLU).
+#include <cstdlib>
+
+#include "metro_common.h"
+
+namespace metro {
+
+typedef _Float16 half_t;
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// (no relocatable device code: every translation unit keeps its own zero page)
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page_slab[4];
+
+typedef __attribute__((address_space(3))) void lds_void3_t;
+
+__device__ __forceinline__ void slab_dma16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_addr)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void slab_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// WM: 32-row cout tiles per wave (TM = WAVES_M*WM*32); pixels: TN = 256 = WAVES_N * WN * 32
+template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int SLAB_ROWS_>
+struct SlabCfg {
+    static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM = WM_, WN = WN_;
+    static constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
+    static constexpr int TM = WAVES_M * WM * 32, TN = WAVES_N * WN * 32;
+    static constexpr int SLAB_ROWS = SLAB_ROWS_;             // padded to a multiple of 8*NW
+    static constexpr int SI = SLAB_ROWS / (8 * NW);          // slab DMA instructions per wave per chunk
+    static constexpr int WI = TM / (8 * NW);                 // weight DMA instructions per wave per step
+    static constexpr int SLAB_BYTES = SLAB_ROWS * 128;
+    static constexpr int ZERO_OFF = 2 * SLAB_BYTES;          // 256-byte zero area behind the slabs
+    static constexpr int W_OFF = ZERO_OFF + 256;
+    static constexpr int W_STAGE_BYTES = TM * 128;
+    static constexpr int W_STAGES = 3;
+    static constexpr int LDS_BYTES = W_OFF + W_STAGES * W_STAGE_BYTES;
+    static constexpr int OUT_ROW_BYTES = TM * 2 + 16;
+    static constexpr int OUT_BYTES = TN * OUT_ROW_BYTES;
+    static_assert(TN == 256, "slab kernel tiles 256 pixels");
+    static_assert(SLAB_ROWS % (8 * NW) == 0 && TM % (8 * NW) == 0, "loader mismatch");
+    static_assert(OUT_BYTES <= 2 * SLAB_BYTES, "epilogue tile must fit in the slab buffers");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
+    ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w,
+    const float* __restrict__ bias, half_t* __restrict__ out, int tiles_m, int halo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = Cfg::NW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / Cfg::WAVES_N;
+    const int wave_n = wave % Cfg::WAVES_N;
+
+    const int nblk = gridDim.x;
+    int lid;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, idx = b >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = lid / tiles_m;
+    const int tile_m = lid % tiles_m;
+    const int m0 = tile_n * Cfg::TN;
+    const int n0 = tile_m * Cfg::TM;
+
+    const int c_in = a.c_in;
+    const int k_total = 9 * c_in;
+    const int kc = (c_in + 63) / 64;
+    const int nq = kc * 9;                         // steps
+    const int hw = a.h_out * a.w_out;
+    const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page_slab);
+    const unsigned smem_base = (unsigned)(size_t)(lds_void3_t*)smem;
+
+    // zero area (read by taps that fall outside the image)
+    if (tid < 16) reinterpret_cast<uint4*>(smem + Cfg::ZERO_OFF)[tid] = make_uint4(0, 0, 0, 0);
+
+    // ---- DMA source coordinates -------------------------------------------------------------
+    const int lrow = lane >> 3, lch = lane & 7;
+    // slab rows: instruction i of this wave fills slab rows (i*NW + wave)*8 + lrow
+    const half_t* ssrc[Cfg::SI];
+    int skoff[Cfg::SI];
+    bool svalid[Cfg::SI];
+#pragma unroll
+    for (int i = 0; i < Cfg::SI; ++i) {
+        const int srow = (i * NW + wave) * 8 + lrow;
+        const int g = m0 - halo + srow;              // flattened pixel index
+        svalid[i] = g >= 0 && g < a.m_total;
+        ssrc[i] = in + (size_t)(svalid[i] ? g : 0) * c_in;
+        skoff[i] = (lch ^ ((srow >> 1) & 7)) * 8;
+    }
+    const half_t* wsrc[Cfg::WI];
+    int wkoff[Cfg::WI];
+    bool wvalid[Cfg::WI];
+#pragma unroll
+    for (int i = 0; i < Cfg::WI; ++i) {
+        const int row = (i * NW + wave) * 8 + lrow;
+        const int co = n0 + row;
+        wvalid[i] = co < a.c_out;
+        wsrc[i] = w + (size_t)(wvalid[i] ? co : 0) * k_total;
+        wkoff[i] = (lch ^ ((row >> 1) & 7)) * 8;
+    }
+
+    auto issue_slab_part = [&](int c, int part) {          // chunk c -> slab buffer c & 1
+        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + (c & 1) * Cfg::SLAB_BYTES + wave * 8 * 128);
+#pragma unroll
+        for (int i = 0; i < Cfg::SI; ++i) {
+            if ((i & 3) != part) continue;
+            const int cc = c * 64 + skoff[i];
+            const half_t* src = (svalid[i] && cc < c_in) ? ssrc[i] + cc : zero;
+            slab_dma16(src, base + i * NW * 8 * 128);
+        }
+    };
+    auto issue_w_part = [&](int q, int part) {             // step q -> ring slot q % 3
+        const int c = q / 9, t = q - c * 9;
+        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + Cfg::W_OFF + (q % 3) * Cfg::W_STAGE_BYTES + wave * 8 * 128);
+        const int kbase = t * c_in + c * 64;
+#pragma unroll
+        for (int i = 0; i < Cfg::WI; ++i) {
+            if ((i & 3) != part) continue;
+            const int cc = c * 64 + wkoff[i];
+            const half_t* src = (wvalid[i] && cc < c_in) ? wsrc[i] + kbase + wkoff[i] : zero;
+            slab_dma16(src, base + i * NW * 8 * 128);
+        }
+    };
+
+    // ---- per-lane tap offsets into the slab (byte offset of the row, or the zero area) ---------
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+    int boff[Cfg::WN][9];
+#pragma unroll
+    for (int j = 0; j < Cfg::WN; ++j) {
+        const int t = (wave_n * Cfg::WN + j) * 32 + frag_row;        // tile-local pixel
+        const int m = m0 + t;
+        const int rem = m % hw;
+        const int h = rem / a.w_out, x = rem - h * a.w_out;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dr = (tap / 3 - 1) * a.dil, ds = (tap % 3 - 1) * a.dil;
+            const bool ok = m < a.m_total && (unsigned)(h + dr) < (unsigned)a.h_out &&
+                            (unsigned)(x + ds) < (unsigned)a.w_out;
+            boff[j][tap] = ok ? (halo + t + dr * a.w_out + ds) * 128 : -1;
+        }
+    }
+
+    floatx16 acc[Cfg::WM][Cfg::WN];
+#pragma unroll
+    for (int i = 0; i < Cfg::WM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- prologue: slab(0), W(0), W(1) ---------------------------------------------------------
+#pragma unroll
+    for (int p = 0; p < 4; ++p) issue_slab_part(0, p);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) issue_w_part(0, p);
+    if (nq > 1) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) issue_w_part(1, p);
+    }
+    __syncthreads();   // zero area visible (plain ds_write above); DMA unaffected (asm, uncounted)
+
+    int c = 0, tap = 0;
+    for (int q = 0; q < nq; ++q) {
+        // younger than W(q): W(q+1), plus slab(c+1) if it was issued during step q-1 (a tap-0 step)
+        const bool w_ahead = q + 1 < nq;
+        const bool slab_ahead = tap == 1 && c + 1 < kc;
+        if (w_ahead && slab_ahead) slab_wait_barrier<Cfg::WI + Cfg::SI>();
+        else if (w_ahead) slab_wait_barrier<Cfg::WI>();
+        else if (slab_ahead) slab_wait_barrier<Cfg::SI>();
+        else slab_wait_barrier<0>();
+
+        const bool issue_w = q + 2 < nq;
+        const bool issue_s = tap == 0 && c + 1 < kc;
+        const char* wl = smem + Cfg::W_OFF + (q % 3) * Cfg::W_STAGE_BYTES;
+        const char* sl = smem + (c & 1) * Cfg::SLAB_BYTES;
+        const char* zl = smem + Cfg::ZERO_OFF;
+        // this step's tap offsets (selected without dynamic register indexing)
+        int bo[Cfg::WN];
+#pragma unroll
+        for (int j = 0; j < Cfg::WN; ++j) {
+            bo[j] = boff[j][0];
+#pragma unroll
+            for (int tt = 1; tt < 9; ++tt) bo[j] = tap == tt ? boff[j][tt] : bo[j];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            half8_t af[Cfg::WM], bf[Cfg::WN];
+            const int chunk = kk * 2 + frag_half;
+#pragma unroll
+            for (int i = 0; i < Cfg::WM; ++i) {
+                const int row = (wave_m * Cfg::WM + i) * 32 + frag_row;
+                af[i] = *reinterpret_cast<const half8_t*>(wl + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < Cfg::WN; ++j) {
+                const char* p = bo[j] >= 0 ? sl + bo[j] + ((chunk ^ ((bo[j] >> 8) & 7)) << 4) : zl;
+                bf[j] = *reinterpret_cast<const half8_t*>(p);
+            }
+#pragma unroll
+            for (int i = 0; i < Cfg::WM; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            if (issue_s) issue_slab_part(c + 1, kk);
+            if (issue_w) issue_w_part(q + 2, kk);
+        }
+        if (++tap == 9) { tap = 0; ++c; }
+    }
+
+    // ---- epilogue: (+bias, ReLU) -> LDS [pixel][cout] -> full-line stores ------------------------
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < Cfg::WM; ++i) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int col = (wave_m * Cfg::WM + i) * 32 + 8 * qd + 4 * frag_half;
+            const int co = n0 + col;
+            floatx4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (co < a.c_out) bv = *reinterpret_cast<const floatx4*>(bias + co);
+#pragma unroll
+            for (int j = 0; j < Cfg::WN; ++j) {
+                const int prow = (wave_n * Cfg::WN + j) * 32 + frag_row;
+                half4_t hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][4 * qd + e] + bv[e];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    hv[e] = (half_t)v;
+                }
+                *reinterpret_cast<half4_t*>(smem + prow * Cfg::OUT_ROW_BYTES + col * 2) = hv;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPRO = Cfg::TM / 8;
+    for (int idx = tid; idx < Cfg::TN * CPRO; idx += Cfg::NT) {
+        const int prow = idx / CPRO;
+        const int ch = idx - prow * CPRO;
+        const int m = m0 + prow;
+        const int co = n0 + ch * 8;
+        if (m >= a.m_total || co >= a.c_out) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16);
+        if (co + 8 <= a.c_out) {
+            *reinterpret_cast<uint4*>(out + (size_t)m * a.c_out + co) = v;
+        } else {
+            const half8_t x = *reinterpret_cast<const half8_t*>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (co + e < a.c_out) out[(size_t)m * a.c_out + co + e] = x[e];
+        }
+    }
+}
+
+template <class Cfg>
+static int launch_slab_cfg(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias,
+                           half_t* out, int halo, hipStream_t stream) {
+    auto kern = conv3x3_f16_slab_kernel<Cfg>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(conv3x3_f16_slab, %d B): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
+            return METRO_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const int tiles_m = (a.c_out + Cfg::TM - 1) / Cfg::TM;
+    const int tiles_n = (a.m_total + Cfg::TN - 1) / Cfg::TN;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, a, in, w, bias,
+                       out, tiles_m, halo);
+    return launch_status("conv3x3_f16_slab");
+}
+
+//                    WAVES_M WAVES_N WM WN slab rows        tile, LDS
+using Slab128r320 = SlabCfg<2, 4, 2, 2, 320>;   // 128 cout x 256 px, halo <= 32:  80 + 48 KiB
+using Slab128r384 = SlabCfg<2, 4, 2, 2, 384>;   // halo <= 64:  96 + 48 KiB
+using Slab64r320 = SlabCfg<1, 8, 2, 1, 320>;    //  64 cout x 256 px
+using Slab64r384 = SlabCfg<1, 8, 2, 1, 384>;
+using Slab64r512 = SlabCfg<1, 8, 2, 1, 512>;    // halo <= 128 (64-wide maps, rate 1): 128 + 24 KiB
+
+bool conv3x3_slab_supported(const MetroConvDesc& d) {
+    static const int enabled = [] { const char* e = getenv("METRO_CONV_SLAB"); return e ? atoi(e) : 0; }();   // off: not yet faster than the generic ring kernel
+    if (!enabled) return false;
+    if (!(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.h_in == d.h_out && d.w_in == d.w_out &&
+          d.pad_top == d.dilation && d.pad_left == d.dilation && !d.has_prologue && !d.has_residual &&
+          d.out_dtype == METRO_F16 && d.in_dtype == METRO_F16 && d.in_pix_stride == d.c_in &&
+          d.c_in % 8 == 0 && d.c_out % 8 == 0))
+        return false;
+    const int halo = d.dilation * d.w_out + d.dilation;
+    const long m = (long)d.n * d.h_out * d.w_out;
+    if (m < 256) return false;
+    if (d.c_out <= 64) return halo <= 128;
+    return halo <= 64;
+}
+
+int launch_conv3x3_slab(const MetroConvDesc& d, const void* in_, const void* w_, const float* bias,
+                        void* out_, hipStream_t stream) {
+    const ConvArgs a = make_conv_args(d);
+    const half_t* in = static_cast<const half_t*>(in_);
+    const half_t* w = static_cast<const half_t*>(w_);
+    half_t* out = static_cast<half_t*>(out_);
+    const int halo = d.dilation * d.w_out + d.dilation;
+    if (d.c_out <= 64) {
+        if (halo <= 32) return launch_slab_cfg<Slab64r320>(a, in, w, bias, out, halo, stream);
+        if (halo <= 64) return launch_slab_cfg<Slab64r384>(a, in, w, bias, out, halo, stream);
+        return launch_slab_cfg<Slab64r512>(a, in, w, bias, out, halo, stream);
+    }
+    if (halo <= 32) return launch_slab_cfg<Slab128r320>(a, in, w, bias, out, halo, stream);
+    return launch_slab_cfg<Slab128r384>(a, in, w, bias, out, halo, stream);
+}
+
+}  // namespace metro

@@ -327,6 +327,8 @@ static int conv_variant() {
 
 int launch_conv_f16(const MetroConvDesc& d, const void* in_, const void* w_, const float* bias,
                     const void* ps_, const void* pb_, const void* res_, void* out, hipStream_t stream) {
+    if (conv_variant() != 0 && conv3x3_slab_supported(d))
+        return launch_conv3x3_slab(d, in_, w_, bias, out, stream);
     if (conv_variant() != 0 && conv_f16_dma_supported(d))
         return launch_conv_f16_dma(d, in_, w_, bias, ps_, pb_, res_, out, stream);
     const ConvArgs a = make_conv_args(d);

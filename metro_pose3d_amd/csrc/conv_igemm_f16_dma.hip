@@ -16,6 +16,7 @@
 //     conv+bias is rounded to fp16 before the shortcut add, exactly the reference's fp16 graph
 //     (BiasAdd output is fp16, then Add: resnet_v2.py:134-138 under tfu.py:426-440).
 #include <cstdlib>
+#include <type_traits>
 
 #include "metro_common.h"
 
@@ -68,16 +69,14 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // is invisible to its bookkeeping; completion is ordered by the counted waits below.
 // lds_addr must be wave-uniform (it goes through M0, saved/restored around the instruction).
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
-    unsigned keep;
+    // M0 is written in the same statement that consumes it and is not preserved: nothing else in
+    // these kernels uses M0 (gfx9+ LDS instructions do not need it).
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_addr)
-        : "memory");
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(gsrc), "s"(lds_addr));   // no "memory" clobber: ordering is carried by the barrier asm
 }
 
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) {
@@ -89,7 +88,7 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <class Cfg, bool PROLOGUE>
+template <class Cfg, bool PROLOGUE, bool FASTK>
 __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w,
     const float* __restrict__ bias, const half_t* __restrict__ pro_scale,
@@ -97,6 +96,8 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     void* __restrict__ out, int out_f32, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = Cfg::BK, STAGES = Cfg::STAGES, NW = Cfg::NW;
+    constexpr int CPR = Cfg::CPR, RPI = Cfg::RPI;
+    constexpr int SLICES = BK / 16;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -142,21 +143,24 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     }
 
     // ---- per-lane DMA source coordinates ----------------------------------------------------
-    constexpr int CPR = Cfg::CPR, RPI = Cfg::RPI;
     const int lrow = lane / CPR;    // row within the RPI-row group one DMA instruction fills
     const int lch = lane % CPR;     // physical 16-byte chunk within the row
-    const half_t* wsrc[Cfg::WI];
-    int wkoff[Cfg::WI];
+    const half_t* wsrc[Cfg::WI];    // FASTK: running pointer; else row base
+    int wkoff[Cfg::WI], winc[Cfg::WI];
     bool wvalid[Cfg::WI];
 #pragma unroll
     for (int i = 0; i < Cfg::WI; ++i) {
         const int row = (i * NW + wave) * RPI + lrow;
         const int co = n0 + row;
         wvalid[i] = co < a.c_out;
-        wsrc[i] = w + (size_t)(wvalid[i] ? co : 0) * k_total;
         wkoff[i] = (lch ^ swzk<BK>(row)) * 8;
+        const half_t* base = w + (size_t)(wvalid[i] ? co : 0) * k_total;
+        // weight rows are contiguous across taps: with c_in % BK == 0 every step is +BK elements
+        wsrc[i] = FASTK ? (wvalid[i] ? base + wkoff[i] : zero) : base;
+        winc[i] = wvalid[i] ? BK : 0;
     }
-    int xh[Cfg::XI], xw[Cfg::XI], xn[Cfg::XI], xkoff[Cfg::XI];
+    int xh[Cfg::XI], xw[Cfg::XI], xn[Cfg::XI], xkoff[Cfg::XI], xinc[Cfg::XI];
+    const half_t* xptr[Cfg::XI];
     bool xvalid[Cfg::XI];
 #pragma unroll
     for (int i = 0; i < Cfg::XI; ++i) {
@@ -172,13 +176,29 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
         xw[i] = wo * a.stride - a.pad_left;
         xn[i] = img * a.h_in * a.w_in;
         xkoff[i] = (lch ^ swzk<BK>(row)) * 8;
+        xptr[i] = zero;
+        xinc[i] = 0;
     }
 
-    // issue state: (tap, c0) of the next step to issue, advanced incrementally
+    // ---- DMA issue ----------------------------------------------------------------------------
+    // The instruction stream around the MFMAs is the scarce resource (PMC: ~100 VALU per K-step were
+    // address arithmetic), so with FASTK (c_in % BK == 0) source pointers are INCREMENTAL: within a
+    // tap every step moves BK channels along a contiguous row; only a new tap recomputes the pixel
+    // pointers; out-of-range lanes sit on the zero page with increment 0.  !FASTK (c_in tail: toy
+    // specs) recomputes everything per step.  One step is issued in SLICES parts so it interleaves
+    // with the MFMA groups of the step being computed.
     int is_tap = 0, is_c0 = 0, is_r = 0, is_s = 0;
-    // One K-step's DMA is issued in SLICES parts so it can be interleaved with the MFMA groups of
-    // the step being computed (a burst right after the barrier leaves the L2 path idle later).
-    constexpr int SLICES = BK / 16;
+    auto x_new_tap = [&]() {
+#pragma unroll
+        for (int i = 0; i < Cfg::XI; ++i) {
+            const int hi = xh[i] + is_r * a.dil;
+            const int wi = xw[i] + is_s * a.dil;
+            const bool ok = xvalid[i] && (unsigned)hi < (unsigned)a.h_in && (unsigned)wi < (unsigned)a.w_in;
+            xptr[i] = ok ? in + (size_t)(xn[i] + hi * a.w_in + wi) * a.in_pix_stride + xkoff[i] : zero;
+            xinc[i] = ok ? BK : 0;
+        }
+    };
+    if (FASTK) x_new_tap();
     unsigned is_wl = 0, is_xl = 0;
     int is_kbase = 0;
     auto issue_begin = [&](int buf) {
@@ -190,20 +210,30 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
 #pragma unroll
         for (int i = 0; i < Cfg::WI; ++i) {
             if ((i % SLICES) != part) continue;
-            const int c = is_c0 + wkoff[i];
-            const half_t* src = (wvalid[i] && c < a.c_in) ? wsrc[i] + is_kbase + wkoff[i] : zero;
-            dma16(src, is_wl + i * NW * RPI * Cfg::ROW_BYTES);
+            if (FASTK) {
+                dma16(wsrc[i], is_wl + i * NW * RPI * Cfg::ROW_BYTES);
+                wsrc[i] += winc[i];
+            } else {
+                const int c = is_c0 + wkoff[i];
+                const half_t* src = (wvalid[i] && c < a.c_in) ? wsrc[i] + is_kbase + wkoff[i] : zero;
+                dma16(src, is_wl + i * NW * RPI * Cfg::ROW_BYTES);
+            }
         }
 #pragma unroll
         for (int i = 0; i < Cfg::XI; ++i) {
             if (((i + Cfg::WI) % SLICES) != part) continue;
-            const int hi = xh[i] + is_r * a.dil;
-            const int wi = xw[i] + is_s * a.dil;
-            const int c = is_c0 + xkoff[i];
-            const bool ok = xvalid[i] && c < a.c_in && (unsigned)hi < (unsigned)a.h_in &&
-                            (unsigned)wi < (unsigned)a.w_in;
-            const half_t* src = ok ? in + (size_t)(xn[i] + hi * a.w_in + wi) * a.in_pix_stride + c : zero;
-            dma16(src, is_xl + i * NW * RPI * Cfg::ROW_BYTES);
+            if (FASTK) {
+                dma16(xptr[i], is_xl + i * NW * RPI * Cfg::ROW_BYTES);
+                xptr[i] += xinc[i];
+            } else {
+                const int hi = xh[i] + is_r * a.dil;
+                const int wi = xw[i] + is_s * a.dil;
+                const int c = is_c0 + xkoff[i];
+                const bool ok = xvalid[i] && c < a.c_in && (unsigned)hi < (unsigned)a.h_in &&
+                                (unsigned)wi < (unsigned)a.w_in;
+                const half_t* src = ok ? in + (size_t)(xn[i] + hi * a.w_in + wi) * a.in_pix_stride + c : zero;
+                dma16(src, is_xl + i * NW * RPI * Cfg::ROW_BYTES);
+            }
         }
     };
     auto issue_end = [&]() {
@@ -212,6 +242,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
             is_c0 = 0;
             ++is_tap;
             if (++is_s == a.kw) { is_s = 0; ++is_r; }
+            if (FASTK && is_tap < taps) x_new_tap();
         }
     };
     auto issue_step = [&](int buf) {
@@ -232,7 +263,8 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     const int frag_row = lane & 31;
     const int frag_half = lane >> 5;
 
-    auto compute_step = [&](int buf, int c0, bool with_issue) {
+    // WITH_ISSUE is a compile-time tag so the step body stays one straight-line basic block
+    auto compute_step = [&](int buf, int c0, auto with_issue) {
         const char* wl = smem + buf * Cfg::STAGE_BYTES;
         const char* xl = wl + Cfg::TM * Cfg::ROW_BYTES;
 #pragma unroll
@@ -261,9 +293,11 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
 #pragma unroll
                 for (int j = 0; j < Cfg::WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            if (with_issue) issue_part(kk);
+            if constexpr (decltype(with_issue)::value) issue_part(kk);
         }
     };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
 
     // ---- main loop: STAGES-1 steps in flight -------------------------------------------------
     if (PROLOGUE) __syncthreads();   // pro_lds written (also drains the ordinary loads above)
@@ -274,7 +308,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
             if (k > 0) wait_vm_and_barrier<0>();      // WAR: everyone is done reading the slot
             issue_step(0);
             wait_vm_and_barrier<0>();                 // RAW: the step has landed for every wave
-            compute_step(0, cc0, false);
+            compute_step(0, cc0, No{});
             cc0 += BK;
             if (cc0 >= a.c_in) cc0 = 0;
         }
@@ -283,20 +317,29 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
         for (int s = 0; s < STAGES - 1; ++s)
             if (s < nk) issue_step(s);
         int cbuf = 0, ibuf = STAGES - 1, cc0 = 0;
-        for (int k = 0; k < nk; ++k) {
-            // steps still allowed in flight once step k has landed
-            const int ahead = nk - 1 - k;
-            if (STAGES >= 4 && ahead >= 2) wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS>();
-            else if (STAGES >= 3 && ahead >= 1) wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS>();
-            else wait_vm_and_barrier<0>();
-            const bool more = k + STAGES - 1 < nk;
-            if (more) issue_begin(ibuf);
-            compute_step(cbuf, cc0, more);
-            if (more) issue_end();
+        auto advance = [&]() {
             cbuf = cbuf + 1 == STAGES ? 0 : cbuf + 1;
             ibuf = ibuf + 1 == STAGES ? 0 : ibuf + 1;
             cc0 += BK;
             if (cc0 >= a.c_in) cc0 = 0;
+        };
+        // steady state: every step has STAGES-2 younger steps in flight and issues one more
+        const int n_main = nk - (STAGES - 1);
+        for (int k = 0; k < n_main; ++k) {
+            wait_vm_and_barrier<(STAGES - 2) * Cfg::LPS>();
+            issue_begin(ibuf);
+            compute_step(cbuf, cc0, Yes{});
+            issue_end();
+            advance();
+        }
+        // tail: nothing left to issue, the in-flight count drains
+        for (int k = n_main < 0 ? 0 : n_main; k < nk; ++k) {
+            const int ahead = nk - 1 - k;
+            if (STAGES >= 4 && ahead >= 2) wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS>();
+            else if (STAGES >= 3 && ahead >= 1) wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS>();
+            else wait_vm_and_barrier<0>();
+            compute_step(cbuf, cc0, No{});
+            advance();
         }
     }
 
@@ -355,6 +398,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     __syncthreads();
     // 2) row-wise: 16 bytes per lane, (+ residual), full-line stores
     constexpr int CPRO = Cfg::TM / 8;                 // 16-byte chunks per tile row
+    const bool res_same = a.res_stride == 1 && a.res_offset == 0 && a.res_h == a.h_out && a.res_w == a.w_out;
     half_t* outh = reinterpret_cast<half_t*>(out);
     for (int idx = tid; idx < Cfg::TN * CPRO; idx += Cfg::NT) {
         const int prow = idx / CPRO;
@@ -364,12 +408,15 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
         if (m >= a.m_total || co >= a.c_out) continue;
         uint4 v = *reinterpret_cast<const uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16);
         if (residual != nullptr) {
-            const int img = m / hw_out;
-            const int rem = m - img * hw_out;
-            const int ho = rem / a.w_out;
-            const int wo = rem - ho * a.w_out;
-            const size_t rp = (size_t)(img * a.res_h + ho * a.res_stride + a.res_offset) * a.res_w +
-                              (wo * a.res_stride + a.res_offset);
+            size_t rp = (size_t)m;                   // same-geometry shortcut: residual pixel == output pixel
+            if (!res_same) {
+                const int img = m / hw_out;
+                const int rem = m - img * hw_out;
+                const int ho = rem / a.w_out;
+                const int wo = rem - ho * a.w_out;
+                rp = (size_t)(img * a.res_h + ho * a.res_stride + a.res_offset) * a.res_w +
+                     (wo * a.res_stride + a.res_offset);
+            }
             if (co + 8 <= a.c_out) {
                 const uint4 rv = *reinterpret_cast<const uint4*>(residual + rp * a.c_out + co);
                 half2_t* x = reinterpret_cast<half2_t*>(&v);
@@ -400,11 +447,11 @@ static int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-template <class Cfg, bool PROLOGUE>
-static int launch_dma_cfg(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias,
-                          const half_t* ps, const half_t* pb, const half_t* res, void* out, int out_f32,
-                          hipStream_t stream) {
-    auto kern = conv_igemm_f16_dma_kernel<Cfg, PROLOGUE>;
+template <class Cfg, bool PROLOGUE, bool FASTK>
+static int launch_dma_cfg2(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias,
+                           const half_t* ps, const half_t* pb, const half_t* res, void* out, int out_f32,
+                           hipStream_t stream) {
+    auto kern = conv_igemm_f16_dma_kernel<Cfg, PROLOGUE, FASTK>;
     constexpr int lds = Cfg::MAIN_BYTES + (PROLOGUE ? Cfg::PRO_BYTES : 0);
     static bool attr_set = false;
     if (!attr_set) {
@@ -423,11 +470,24 @@ static int launch_dma_cfg(const ConvArgs& a, const half_t* in, const half_t* w, 
     return launch_status("conv_igemm_f16_dma");
 }
 
+template <class Cfg, bool PROLOGUE>
+static int launch_dma_cfg(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias,
+                          const half_t* ps, const half_t* pb, const half_t* res, void* out, int out_f32,
+                          hipStream_t stream) {
+    // FASTK needs whole K steps per tap and 16-byte-aligned weight rows for the running pointers
+    if (a.c_in % Cfg::BK == 0)
+        return launch_dma_cfg2<Cfg, PROLOGUE, true>(a, in, w, bias, ps, pb, res, out, out_f32, stream);
+    return launch_dma_cfg2<Cfg, PROLOGUE, false>(a, in, w, bias, ps, pb, res, out, out_f32, stream);
+}
+
 //                        WAVES_M WAVES_N WM WN STAGES BK   tile (cout x pixels), waves, LDS
 using Dma128x256s3 = DmaCfg<2, 4, 2, 2, 3>;        // 128 x 256, 8 waves, 144 KiB: deep-K, >= 256 tiles
 using Dma128x128s4 = DmaCfg<2, 4, 2, 1, 4>;        // 128 x 128, 8 waves, 128 KiB: deep-K, few tiles
 using Dma128x128s2 = DmaCfg<2, 4, 2, 1, 2>;        // 128 x 128, 8 waves,  64 KiB: 2 blocks / CU
 using Dma128x128s1 = DmaCfg<2, 4, 2, 1, 1>;        // 128 x 128, 8 waves,  34 KiB: 3 blocks / CU (K <= 64)
+using Dma256x256s2 = DmaCfg<2, 4, 4, 2, 2>;        // 256 x 256, 8 waves, 128 KiB: wide layers, half the L2->LDS bytes per FLOP
+using Dma256x256s4k32 = DmaCfg<2, 4, 4, 2, 4, 32>; // same tile, BK 32, 4 stages
+using Dma128x256s3k32 = DmaCfg<2, 4, 2, 2, 3, 32>; // 128 x 256, BK 32, 72 KiB: 2 blocks / CU (epilogue of one overlaps the loop of the other)
 using Dma64x128s3 = DmaCfg<1, 4, 2, 1, 3>;         //  64 x 128, 4 waves,  72 KiB
 using Dma64x128s1 = DmaCfg<1, 4, 2, 1, 1>;         //  64 x 128, 4 waves,  24 KiB
 using Dma64x128s3k32 = DmaCfg<1, 4, 2, 1, 3, 32>;  //  64 x 128, 4 waves, BK 32 (the stem's 32-wide taps)
@@ -450,7 +510,7 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
     const bool pro = d.has_prologue != 0;
     const int tiles128 = (d.c_out + 127) / 128;
     // tuning knobs (A/B runs): K-steps up to which the 1-stage / 2-stage 128x128 configs are used
-    static const int nk_s1 = env_int("METRO_NK_S1", 1);
+    static const int nk_s1 = env_int("METRO_NK_S1", 2);
     static const int nk_s2 = env_int("METRO_NK_S2", 8);
 #define METRO_DMA(CFG)                                                                         \
     return pro ? launch_dma_cfg<CFG, true>(a, in, w, bias, ps, pb, res, out, out_f32, stream)  \
@@ -464,9 +524,19 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
         METRO_DMA(Dma64x128s3);
     }
     if (nk <= nk_s1) { METRO_DMA(Dma128x128s1); }
+    static const int k32 = env_int("METRO_DMA_K32", 8);
+    {
+        const long b256 = (long)tiles128 * ((a.m_total + 255) / 256);
+        if (k32 && nk <= k32 && b256 >= 512) { METRO_DMA(Dma128x256s3k32); }
+    }
     if (nk <= nk_s2) { METRO_DMA(Dma128x128s2); }
     // 256-pixel tiles only when they still give every CU a block
     const long blocks256 = (long)tiles128 * ((a.m_total + 255) / 256);
+    static const int big = env_int("METRO_DMA_BIG", 2);
+    if (big && d.c_out % 256 == 0 && blocks256 / 2 >= 256) {
+        if (big == 1) { METRO_DMA(Dma256x256s2); }
+        METRO_DMA(Dma256x256s4k32);
+    }
     if (blocks256 >= 256) { METRO_DMA(Dma128x256s3); }
     METRO_DMA(Dma128x128s4);
 #undef METRO_DMA

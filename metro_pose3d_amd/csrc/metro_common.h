@@ -74,6 +74,10 @@ bool conv_f16_dma_supported(const MetroConvDesc& d);
 int launch_conv_f16_dma(const MetroConvDesc& d, const void* in, const void* w, const float* bias,
                         const void* pro_scale, const void* pro_shift, const void* residual, void* out,
                         hipStream_t stream);
+// 3x3 stride-1 convs with tap reuse from an LDS-resident activation slab
+bool conv3x3_slab_supported(const MetroConvDesc& d);
+int launch_conv3x3_slab(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out,
+                        hipStream_t stream);
 int launch_conv_f64acc(const MetroConvDesc& d, const void* in, const double* w, const double* bias,
                        const double* pro_scale, const double* pro_shift, const void* residual,
                        void* out, hipStream_t stream);

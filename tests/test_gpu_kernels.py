@@ -29,6 +29,13 @@ CONV_CASES = [
     ('3x3_s2_centered', 2, 32, 64, 64, 3, 2, 1, 0, 16),
     ('3x3_big', 4, 32, 128, 256, 3, 1, 1, 1, 32),
     ('1x1_s2_shifted', 2, 16, 64, 128, 1, 2, 1, -1, 8),
+    # tap-reuse slab kernel: tiles spanning several 8x8 images (ragged last tile), 64-wide maps,
+    # c_in tail + c_out not a multiple of the tile, rate 2 on 16x16 maps (the stride-16 block4 shape)
+    ('3x3_slab_8x8_ragged', 6, 8, 64, 128, 3, 1, 1, 1, 8),
+    ('3x3_slab_64map', 1, 64, 64, 64, 3, 1, 1, 1, 64),
+    ('3x3_slab_cin96_cout192', 2, 16, 96, 192, 3, 1, 1, 1, 16),
+    ('3x3_slab_rate2_512', 3, 16, 128, 256, 3, 1, 2, 2, 16),
+    ('3x3_slab_32map', 2, 32, 128, 128, 3, 1, 1, 1, 32),
 ]
 
 
