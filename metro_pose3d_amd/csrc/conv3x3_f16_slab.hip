@@ -16,6 +16,7 @@
 // Covers the reference's conv2 call sites with stride 1: resnet_v2.py:130-132 via
 // resnet_utils.conv2d_same (SAME padding, rate r).  Post-conv BN+ReLU folded (bias + ReLU).
 #include <cstdlib>
+#include <type_traits>
 
 #include "metro_common.h"
 
@@ -33,16 +34,12 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page_slab[4];
 typedef __attribute__((address_space(3))) void lds_void3_t;
 
 __device__ __forceinline__ void slab_dma16(const void* gsrc, unsigned lds_addr) {
-    unsigned keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_addr)
-        : "memory");
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(gsrc), "s"(lds_addr));
 }
 
 template <int N>
@@ -134,26 +131,35 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
         wkoff[i] = (lch ^ ((row >> 1) & 7)) * 8;
     }
 
-    auto issue_slab_part = [&](int c, int part) {          // chunk c -> slab buffer c & 1
-        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + (c & 1) * Cfg::SLAB_BYTES + wave * 8 * 128);
+    // running DMA pointers (c_in % 64 == 0 is required by the launcher): the slab advances 64
+    // channels per chunk; a weight row advances c_in per tap and wraps to the next chunk after 9 taps
+    const half_t* sptr[Cfg::SI];
+#pragma unroll
+    for (int i = 0; i < Cfg::SI; ++i) sptr[i] = svalid[i] ? ssrc[i] + skoff[i] : zero;
+    const half_t* wptr[Cfg::WI];
+#pragma unroll
+    for (int i = 0; i < Cfg::WI; ++i) wptr[i] = wvalid[i] ? wsrc[i] + wkoff[i] : zero;
+    const int w_tap_inc = c_in;                 // elements, tap t -> t+1
+    const int w_chunk_inc = 64 - 8 * c_in;      // elements, (c, 8) -> (c+1, 0)
+
+    auto issue_slab_part = [&](int buf, int part, bool last_part) {     // next chunk -> slab buffer `buf`
+        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + buf * Cfg::SLAB_BYTES + wave * 8 * 128);
 #pragma unroll
         for (int i = 0; i < Cfg::SI; ++i) {
             if ((i & 3) != part) continue;
-            const int cc = c * 64 + skoff[i];
-            const half_t* src = (svalid[i] && cc < c_in) ? ssrc[i] + cc : zero;
-            slab_dma16(src, base + i * NW * 8 * 128);
+            slab_dma16(sptr[i], base + i * NW * 8 * 128);
+            sptr[i] += svalid[i] ? 64 : 0;
         }
+        (void)last_part;
     };
-    auto issue_w_part = [&](int q, int part) {             // step q -> ring slot q % 3
-        const int c = q / 9, t = q - c * 9;
-        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + Cfg::W_OFF + (q % 3) * Cfg::W_STAGE_BYTES + wave * 8 * 128);
-        const int kbase = t * c_in + c * 64;
+    // issues W of the step whose (tap) is `t_issue`, into ring slot `slot`
+    auto issue_w_part = [&](int slot, int t_issue, int part) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + Cfg::W_OFF + slot * Cfg::W_STAGE_BYTES + wave * 8 * 128);
 #pragma unroll
         for (int i = 0; i < Cfg::WI; ++i) {
             if ((i & 3) != part) continue;
-            const int cc = c * 64 + wkoff[i];
-            const half_t* src = (wvalid[i] && cc < c_in) ? wsrc[i] + kbase + wkoff[i] : zero;
-            slab_dma16(src, base + i * NW * 8 * 128);
+            slab_dma16(wptr[i], base + i * NW * 8 * 128);
+            wptr[i] += wvalid[i] ? (t_issue == 8 ? w_chunk_inc : w_tap_inc) : 0;
         }
     };
 
@@ -185,38 +191,22 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
 
     // ---- prologue: slab(0), W(0), W(1) ---------------------------------------------------------
 #pragma unroll
-    for (int p = 0; p < 4; ++p) issue_slab_part(0, p);
+    for (int p = 0; p < 4; ++p) issue_slab_part(0, p, false);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) issue_w_part(0, p);
-    if (nq > 1) {
+    for (int p = 0; p < 4; ++p) issue_w_part(0, 0, p);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) issue_w_part(1, p);
-    }
+    for (int p = 0; p < 4; ++p) issue_w_part(1, 1, p);
     __syncthreads();   // zero area visible (plain ds_write above); DMA unaffected (asm, uncounted)
 
-    int c = 0, tap = 0;
-    for (int q = 0; q < nq; ++q) {
-        // younger than W(q): W(q+1), plus slab(c+1) if it was issued during step q-1 (a tap-0 step)
-        const bool w_ahead = q + 1 < nq;
-        const bool slab_ahead = tap == 1 && c + 1 < kc;
-        if (w_ahead && slab_ahead) slab_wait_barrier<Cfg::WI + Cfg::SI>();
-        else if (w_ahead) slab_wait_barrier<Cfg::WI>();
-        else if (slab_ahead) slab_wait_barrier<Cfg::SI>();
-        else slab_wait_barrier<0>();
-
-        const bool issue_w = q + 2 < nq;
-        const bool issue_s = tap == 0 && c + 1 < kc;
-        const char* wl = smem + Cfg::W_OFF + (q % 3) * Cfg::W_STAGE_BYTES;
-        const char* sl = smem + (c & 1) * Cfg::SLAB_BYTES;
+    // One (chunk, tap) step.  TAP, the ring slot and what gets issued are compile-time, so each
+    // step is straight-line code: 16 ds_read_b128 + 16 MFMA + its share of the DMA issue.
+    auto step = [&](auto tap_c, auto issue_slab_c, auto issue_w_c, auto wait_c, int slab_buf, int wslot) {
+        constexpr int TAP = decltype(tap_c)::value;
+        slab_wait_barrier<decltype(wait_c)::value>();
+        const char* wl = smem + Cfg::W_OFF + wslot * Cfg::W_STAGE_BYTES;
+        const char* sl = smem + slab_buf * Cfg::SLAB_BYTES;
         const char* zl = smem + Cfg::ZERO_OFF;
-        // this step's tap offsets (selected without dynamic register indexing)
-        int bo[Cfg::WN];
-#pragma unroll
-        for (int j = 0; j < Cfg::WN; ++j) {
-            bo[j] = boff[j][0];
-#pragma unroll
-            for (int tt = 1; tt < 9; ++tt) bo[j] = tap == tt ? boff[j][tt] : bo[j];
-        }
+        const int islot = wslot == 0 ? 2 : wslot - 1;          // slot of step q+2 == slot of step q-1
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             half8_t af[Cfg::WM], bf[Cfg::WN];
@@ -228,7 +218,8 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
             }
 #pragma unroll
             for (int j = 0; j < Cfg::WN; ++j) {
-                const char* p = bo[j] >= 0 ? sl + bo[j] + ((chunk ^ ((bo[j] >> 8) & 7)) << 4) : zl;
+                const int bo = boff[j][TAP];
+                const char* p = bo >= 0 ? sl + bo + ((chunk ^ ((bo >> 8) & 7)) << 4) : zl;
                 bf[j] = *reinterpret_cast<const half8_t*>(p);
             }
 #pragma unroll
@@ -236,11 +227,39 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
 #pragma unroll
                 for (int j = 0; j < Cfg::WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            if (issue_s) issue_slab_part(c + 1, kk);
-            if (issue_w) issue_w_part(q + 2, kk);
+            if constexpr (decltype(issue_slab_c)::value) issue_slab_part(slab_buf ^ 1, kk, kk == 3);
+            if constexpr (decltype(issue_w_c)::value) issue_w_part(islot, (TAP + 2) % 9, kk);
         }
-        if (++tap == 9) { tap = 0; ++c; }
-    }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    auto I = [](auto v) { return v; };
+    // a whole chunk: 9 taps, slots cycle 0,1,2 (9 % 3 == 0 so every chunk starts on slot 0)
+    auto chunk_main = [&](int slab_buf) {       // not the last chunk: slab(c+1) at tap 0, W always
+        step(std::integral_constant<int, 0>{}, T{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
+        step(std::integral_constant<int, 1>{}, F{}, T{}, std::integral_constant<int, Cfg::WI + Cfg::SI>{}, slab_buf, 1);
+        step(std::integral_constant<int, 2>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
+        step(std::integral_constant<int, 3>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
+        step(std::integral_constant<int, 4>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
+        step(std::integral_constant<int, 5>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
+        step(std::integral_constant<int, 6>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
+        step(std::integral_constant<int, 7>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
+        step(std::integral_constant<int, 8>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
+    };
+    auto chunk_last = [&](int slab_buf) {       // last chunk: no slab, W stops two steps before the end
+        step(std::integral_constant<int, 0>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
+        step(std::integral_constant<int, 1>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
+        step(std::integral_constant<int, 2>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
+        step(std::integral_constant<int, 3>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
+        step(std::integral_constant<int, 4>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
+        step(std::integral_constant<int, 5>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
+        step(std::integral_constant<int, 6>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
+        step(std::integral_constant<int, 7>{}, F{}, F{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
+        step(std::integral_constant<int, 8>{}, F{}, F{}, std::integral_constant<int, 0>{}, slab_buf, 2);
+    };
+    (void)I; (void)nq;
+    for (int c = 0; c + 1 < kc; ++c) chunk_main(c & 1);
+    chunk_last((kc - 1) & 1);
 
     // ---- epilogue: (+bias, ReLU) -> LDS [pixel][cout] -> full-line stores ------------------------
     __syncthreads();
@@ -315,18 +334,18 @@ using Slab64r384 = SlabCfg<1, 8, 2, 1, 384>;
 using Slab64r512 = SlabCfg<1, 8, 2, 1, 512>;    // halo <= 128 (64-wide maps, rate 1): 128 + 24 KiB
 
 bool conv3x3_slab_supported(const MetroConvDesc& d) {
-    static const int enabled = [] { const char* e = getenv("METRO_CONV_SLAB"); return e ? atoi(e) : 0; }();   // off: not yet faster than the generic ring kernel
+    static const int enabled = [] { const char* e = getenv("METRO_CONV_SLAB"); return e ? atoi(e) : 1; }();
     if (!enabled) return false;
     if (!(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.h_in == d.h_out && d.w_in == d.w_out &&
           d.pad_top == d.dilation && d.pad_left == d.dilation && !d.has_prologue && !d.has_residual &&
           d.out_dtype == METRO_F16 && d.in_dtype == METRO_F16 && d.in_pix_stride == d.c_in &&
-          d.c_in % 8 == 0 && d.c_out % 8 == 0))
+          d.c_in % 64 == 0 && d.c_out % 8 == 0))
         return false;
     const int halo = d.dilation * d.w_out + d.dilation;
     const long m = (long)d.n * d.h_out * d.w_out;
     if (m < 256) return false;
     if (d.c_out <= 64) return halo <= 128;
-    return halo <= 64;
+    return halo <= 64;   // (the 64-cout tiles used for few-tile layers allow more, kept equal for simplicity)
 }
 
 int launch_conv3x3_slab(const MetroConvDesc& d, const void* in_, const void* w_, const float* bias,
@@ -336,7 +355,9 @@ int launch_conv3x3_slab(const MetroConvDesc& d, const void* in_, const void* w_,
     const half_t* w = static_cast<const half_t*>(w_);
     half_t* out = static_cast<half_t*>(out_);
     const int halo = d.dilation * d.w_out + d.dilation;
-    if (d.c_out <= 64) {
+    // 64-cout tiles when 128-cout tiles would leave CUs without a block (256 CUs)
+    const long blocks128 = (long)((d.c_out + 127) / 128) * ((a.m_total + 255) / 256);
+    if (d.c_out <= 64 || blocks128 < 256) {
         if (halo <= 32) return launch_slab_cfg<Slab64r320>(a, in, w, bias, out, halo, stream);
         if (halo <= 64) return launch_slab_cfg<Slab64r384>(a, in, w, bias, out, halo, stream);
         return launch_slab_cfg<Slab64r512>(a, in, w, bias, out, halo, stream);
