@@ -176,6 +176,21 @@ def main():
                         f'{li.out_bytes_per_image * b / 1e6:.2f}\n')
             f.write(f'TOTAL\t-\t{layer_ms.sum():.4f}\t{conv_flops / 1e9:.3f}\t{conv_flops / 1e9 / layer_ms.sum():.1f}\t-\n')
 
+    # HBM traffic of the conv launches comes from a COMMITTED rocprofv3 PMC run of this same command
+    # (counters cannot be collected from inside the process being profiled): profiles/*_pmc_traffic.json
+    traffic = None
+    traffic_note = None
+    if rank == 0 and (args.arch, args.stride, args.dataset, b, args.precision) == (50, 16, 'h36m', 64, 'f16'):
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+        if files:
+            with open(files[-1]) as f:
+                t = json.load(f)
+            traffic = t['conv_hbm_bytes_per_forward']
+            traffic_note = (f'HBM bytes per forward summed over the {t["conv_launches"]} conv launches, '
+                            f'(2*FETCH_SIZE + WRITE_SIZE)*1024 from {os.path.basename(files[-1])} '
+                            f'(rocprofv3 --pmc, separate passes; avg per launch {t["conv_hbm_bytes_per_launch_avg"]:.3e} B; '
+                            f'one-round-trip-per-layer minimum {t["algorithmic_min_bytes_per_forward_fp16_every_layer_roundtrip"]:.3e} B)')
     if rank == 0:
         total_crops = b * world * args.steps
         ms_per_step = elapsed * 1e3 / args.steps
@@ -197,7 +212,8 @@ def main():
             'whole_path_tflops': round(eng.flops_per_image * value / world / 1e12, 2),
             'roofline': {'bound': 'mfma', 'kernel': f'conv_igemm_f16 ({n_conv} launches per forward)',
                          'achieved': round(achieved_tflops, 2), 'peak': PEAK_F16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved_tflops / PEAK_F16_DENSE_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved_tflops / PEAK_F16_DENSE_TFLOPS, 4), 'traffic': traffic,
+                         'traffic_note': traffic_note,
                          'ms_per_forward_in_kernel': round(conv_ms, 4),
                          'algorithmic_gflop_per_forward': round(conv_flops / 1e9, 3)},
         }

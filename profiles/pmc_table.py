@@ -42,7 +42,7 @@ def main():
     meta = {}
     for p in sorted(os.listdir(base)):
         d = os.path.join(base, p)
-        if not os.path.isdir(d):
+        if not os.path.isdir(d) or not glob.glob(os.path.join(d, '*_counter_collection.csv')):
             continue
         rows = load(d)
         rows = rows[fwd * per:(fwd + 1) * per]
