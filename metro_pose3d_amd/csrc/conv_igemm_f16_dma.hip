@@ -299,6 +299,44 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
 
+    // ---- residual prefetch -------------------------------------------------------------------
+    // The shortcut tile is loaded into registers in the layout of the row-wise epilogue (16 bytes
+    // per lane), issued right AFTER the last LDS-DMA of the block (start of the drain phase): VMEM
+    // returns in order, so loads issued earlier would hold up the ring's first stages behind their
+    // HBM latency.  Being younger than every DMA, they stay in flight across the drain steps: the
+    // drain waits count them in (vmcnt(N + EPI_ITERS)).
+    constexpr int CPRO = Cfg::TM / 8;                 // 16-byte chunks per tile row
+    constexpr int EPI_ITERS = Cfg::TN * CPRO / Cfg::NT;
+    static_assert(Cfg::TN * CPRO % Cfg::NT == 0, "epilogue loop must divide evenly");
+    const bool res_same = a.res_stride == 1 && a.res_offset == 0 && a.res_h == a.h_out && a.res_w == a.w_out;
+    const bool has_res = residual != nullptr && !out_f32;
+    uint4 rres[EPI_ITERS];
+#pragma unroll
+    for (int it = 0; it < EPI_ITERS; ++it) rres[it] = make_uint4(0, 0, 0, 0);
+    auto prefetch_residual = [&]() {
+#pragma unroll
+        for (int it = 0; it < EPI_ITERS; ++it) {
+            const int idx = tid + it * Cfg::NT;
+            const int prow = idx / CPRO;
+            const int ch = idx - prow * CPRO;
+            const int m = m0 + prow;
+            const int co = n0 + ch * 8;
+            // every lane issues exactly one load per iteration (clamped address) so that the
+            // per-wave VMEM count the drain waits rely on is uniform
+            const bool ok = m < a.m_total && co + 8 <= a.c_out;
+            size_t rp = ok ? (size_t)m : 0;          // same-geometry shortcut: residual pixel == output pixel
+            if (!res_same && ok) {
+                const int img = m / hw_out;
+                const int rem = m - img * hw_out;
+                const int ho = rem / a.w_out;
+                const int wo = rem - ho * a.w_out;
+                rp = (size_t)(img * a.res_h + ho * a.res_stride + a.res_offset) * a.res_w +
+                     (wo * a.res_stride + a.res_offset);
+            }
+            rres[it] = *reinterpret_cast<const uint4*>(residual + rp * a.c_out + (ok ? co : 0));
+        }
+    };
+
     // ---- main loop: STAGES-1 steps in flight -------------------------------------------------
     if (PROLOGUE) __syncthreads();   // pro_lds written (also drains the ordinary loads above)
     if constexpr (STAGES == 1) {
@@ -307,7 +345,12 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
         for (int k = 0; k < nk; ++k) {
             if (k > 0) wait_vm_and_barrier<0>();      // WAR: everyone is done reading the slot
             issue_step(0);
-            wait_vm_and_barrier<0>();                 // RAW: the step has landed for every wave
+            if (has_res && k == nk - 1) {
+                prefetch_residual();
+                wait_vm_and_barrier<EPI_ITERS>();     // the step has landed; the residual may still fly
+            } else {
+                wait_vm_and_barrier<0>();             // RAW: the step has landed for every wave
+            }
             compute_step(0, cc0, No{});
             cc0 += BK;
             if (cc0 >= a.c_in) cc0 = 0;
@@ -332,12 +375,19 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
             issue_end();
             advance();
         }
-        // tail: nothing left to issue, the in-flight count drains
+        // drain: nothing left to issue, the in-flight count runs down (residual loads ride along)
+        if (has_res) prefetch_residual();
         for (int k = n_main < 0 ? 0 : n_main; k < nk; ++k) {
             const int ahead = nk - 1 - k;
-            if (STAGES >= 4 && ahead >= 2) wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS>();
-            else if (STAGES >= 3 && ahead >= 1) wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS>();
-            else wait_vm_and_barrier<0>();
+            if (has_res) {
+                if (STAGES >= 4 && ahead >= 2) wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS + EPI_ITERS>();
+                else if (STAGES >= 3 && ahead >= 1) wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS + EPI_ITERS>();
+                else wait_vm_and_barrier<EPI_ITERS>();
+            } else {
+                if (STAGES >= 4 && ahead >= 2) wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS>();
+                else if (STAGES >= 3 && ahead >= 1) wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS>();
+                else wait_vm_and_barrier<0>();
+            }
             compute_step(cbuf, cc0, No{});
             advance();
         }
@@ -396,44 +446,27 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
         }
     }
     __syncthreads();
-    // 2) row-wise: 16 bytes per lane, (+ residual), full-line stores
-    constexpr int CPRO = Cfg::TM / 8;                 // 16-byte chunks per tile row
-    const bool res_same = a.res_stride == 1 && a.res_offset == 0 && a.res_h == a.h_out && a.res_w == a.w_out;
+    // 2) row-wise: 16 bytes per lane, (+ prefetched residual), full-line stores
     half_t* outh = reinterpret_cast<half_t*>(out);
-    for (int idx = tid; idx < Cfg::TN * CPRO; idx += Cfg::NT) {
+#pragma unroll
+    for (int it = 0; it < EPI_ITERS; ++it) {
+        const int idx = tid + it * Cfg::NT;
         const int prow = idx / CPRO;
         const int ch = idx - prow * CPRO;
         const int m = m0 + prow;
         const int co = n0 + ch * 8;
         if (m >= a.m_total || co >= a.c_out) continue;
         uint4 v = *reinterpret_cast<const uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16);
-        if (residual != nullptr) {
-            size_t rp = (size_t)m;                   // same-geometry shortcut: residual pixel == output pixel
-            if (!res_same) {
-                const int img = m / hw_out;
-                const int rem = m - img * hw_out;
-                const int ho = rem / a.w_out;
-                const int wo = rem - ho * a.w_out;
-                rp = (size_t)(img * a.res_h + ho * a.res_stride + a.res_offset) * a.res_w +
-                     (wo * a.res_stride + a.res_offset);
-            }
-            if (co + 8 <= a.c_out) {
-                const uint4 rv = *reinterpret_cast<const uint4*>(residual + rp * a.c_out + co);
+        if (co + 8 <= a.c_out) {
+            if (residual != nullptr) {
                 half2_t* x = reinterpret_cast<half2_t*>(&v);
-                const half2_t* r = reinterpret_cast<const half2_t*>(&rv);
+                const half2_t* r = reinterpret_cast<const half2_t*>(&rres[it]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = x[e] + r[e];    // fp16 Add, like the reference graph
-            } else {
-                half8_t x = *reinterpret_cast<half8_t*>(&v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (co + e < a.c_out) x[e] = x[e] + residual[rp * a.c_out + co + e];
-                v = *reinterpret_cast<uint4*>(&x);
             }
-        }
-        if (co + 8 <= a.c_out) {
             *reinterpret_cast<uint4*>(outh + (size_t)m * a.c_out + co) = v;
         } else {
+            // ragged channel tail (c_out % 8 != 0 never carries a residual: see conv_f16_dma_supported)
             const half8_t x = *reinterpret_cast<const half8_t*>(&v);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
