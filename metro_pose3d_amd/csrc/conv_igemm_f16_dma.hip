@@ -515,6 +515,7 @@ static int launch_dma_cfg(const ConvArgs& a, const half_t* in, const half_t* w, 
 
 //                        WAVES_M WAVES_N WM WN STAGES BK   tile (cout x pixels), waves, LDS
 using Dma128x256s3 = DmaCfg<2, 4, 2, 2, 3>;        // 128 x 256, 8 waves, 144 KiB: deep-K, >= 256 tiles
+using Dma128x256s3p = DmaCfg<1, 8, 4, 1, 3>;       // 128 x 256, waves 1x8 (wave tile 128 cout x 32 px): each prologue'd pixel fragment feeds 4 MFMAs
 using Dma128x128s4 = DmaCfg<2, 4, 2, 1, 4>;        // 128 x 128, 8 waves, 128 KiB: deep-K, few tiles
 using Dma128x128s2 = DmaCfg<2, 4, 2, 1, 2>;        // 128 x 128, 8 waves,  64 KiB: 2 blocks / CU
 using Dma128x128s1 = DmaCfg<2, 4, 2, 1, 1>;        // 128 x 128, 8 waves,  34 KiB: 3 blocks / CU (K <= 64)
@@ -552,7 +553,11 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
         return launch_dma_cfg<Dma64x128s3k32, false>(a, in, w, bias, ps, pb, res, out, out_f32, stream);
     }
     const int nk = d.kh * d.kw * ((d.c_in + 63) / 64);
-    if (d.c_out <= 64) {
+    // 64-cout tiles: narrow layers, and heads whose width wastes most of a second 128-tile (136 = 8*17)
+    static const int head64 = env_int("METRO_DMA_HEAD64", 1);
+    const bool narrow = d.c_out <= 64 || (head64 && d.c_out < 256 && d.c_out % 128 != 0 && (d.c_out % 128) <= 64 &&
+                                          d.c_out / 128 <= 1);
+    if (narrow) {
         if (nk <= nk_s1) { METRO_DMA(Dma64x128s1); }
         METRO_DMA(Dma64x128s3);
     }
@@ -569,6 +574,10 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
     if (big && d.c_out % 256 == 0 && blocks256 / 2 >= 256) {
         if (big == 1) { METRO_DMA(Dma256x256s2); }
         METRO_DMA(Dma256x256s4k32);
+    }
+    static const int pro_cfg = env_int("METRO_DMA_PRO", 0);
+    if (blocks256 >= 256 && pro && pro_cfg) {
+        return launch_dma_cfg<Dma128x256s3p, true>(a, in, w, bias, ps, pb, res, out, out_f32, stream);
     }
     if (blocks256 >= 256) { METRO_DMA(Dma128x256s3); }
     METRO_DMA(Dma128x128s4);
