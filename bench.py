@@ -106,11 +106,18 @@ def main():
         print('bench.py: no HIP device visible; the hot path has no CPU fallback', file=sys.stderr)
         sys.exit(2)
     import torch.distributed as dist
-    device = torch.device('cuda', local_rank)
+    # debug overrides (single-GPU boxes): METRO_BENCH_SAME_GPU=1 puts every rank on cuda:0,
+    # METRO_BENCH_BACKEND=gloo swaps RCCL for gloo so the N>1 control flow can be exercised anywhere
+    same_gpu = os.environ.get('METRO_BENCH_SAME_GPU') == '1'
+    backend = os.environ.get('METRO_BENCH_BACKEND', 'nccl')
+    device = torch.device('cuda', 0 if same_gpu else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from metro_pose3d_amd import ModelSpec, synth
     from metro_pose3d_amd.engine import Engine
@@ -125,15 +132,26 @@ def main():
     images = torch.from_numpy(synth.make_images(b, spec.proc_side, seed=1234 + rank)).to(device)
     jout = spec.skeleton.n_out
     local = torch.empty((b, jout, 3), dtype=torch.float32, device=device)
-    gathered = torch.empty((b * world, jout, 3), dtype=torch.float32, device=device) if world > 1 else None
+    gatherer = None
+    if world > 1:
+        from metro_pose3d_amd.dist import OverlappedPoseGather
+        gatherer = OverlappedPoseGather(b, jout, world, device)
+    step_no = [0]
 
     def step():
-        eng.forward(images, out=local)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, local)      # ncclAllGather over xGMI
+            # one ncclAllGather (RCCL over xGMI) per step, overlapped with the next step's forward
+            i = step_no[0]
+            eng.forward(images, out=gatherer.local_buffer(i))
+            gatherer.submit(i)
+            step_no[0] = i + 1
+        else:
+            eng.forward(images, out=local)
 
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        gatherer.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -143,6 +161,9 @@ def main():
     ev0.record()
     for _ in range(args.steps):
         step()
+    if world > 1:
+        gatherer.finish()                                     # every gather of the timed steps has completed
+        local = gatherer.local[(step_no[0] - 1) % gatherer.depth]
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:

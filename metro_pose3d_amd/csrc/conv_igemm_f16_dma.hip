@@ -515,11 +515,9 @@ static int launch_dma_cfg(const ConvArgs& a, const half_t* in, const half_t* w, 
 
 //                        WAVES_M WAVES_N WM WN STAGES BK   tile (cout x pixels), waves, LDS
 using Dma128x256s3 = DmaCfg<2, 4, 2, 2, 3>;        // 128 x 256, 8 waves, 144 KiB: deep-K, >= 256 tiles
-using Dma128x256s3p = DmaCfg<1, 8, 4, 1, 3>;       // 128 x 256, waves 1x8 (wave tile 128 cout x 32 px): each prologue'd pixel fragment feeds 4 MFMAs
 using Dma128x128s4 = DmaCfg<2, 4, 2, 1, 4>;        // 128 x 128, 8 waves, 128 KiB: deep-K, few tiles
 using Dma128x128s2 = DmaCfg<2, 4, 2, 1, 2>;        // 128 x 128, 8 waves,  64 KiB: 2 blocks / CU
 using Dma128x128s1 = DmaCfg<2, 4, 2, 1, 1>;        // 128 x 128, 8 waves,  34 KiB: 3 blocks / CU (K <= 64)
-using Dma256x256s2 = DmaCfg<2, 4, 4, 2, 2>;        // 256 x 256, 8 waves, 128 KiB: wide layers, half the L2->LDS bytes per FLOP
 using Dma256x256s4k32 = DmaCfg<2, 4, 4, 2, 4, 32>; // same tile, BK 32, 4 stages
 using Dma128x256s3k32 = DmaCfg<2, 4, 2, 2, 3, 32>; // 128 x 256, BK 32, 72 KiB: 2 blocks / CU (epilogue of one overlaps the loop of the other)
 using Dma64x128s3 = DmaCfg<1, 4, 2, 1, 3>;         //  64 x 128, 4 waves,  72 KiB
@@ -571,14 +569,7 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
     // 256-pixel tiles only when they still give every CU a block
     const long blocks256 = (long)tiles128 * ((a.m_total + 255) / 256);
     static const int big = env_int("METRO_DMA_BIG", 2);
-    if (big && d.c_out % 256 == 0 && blocks256 / 2 >= 256) {
-        if (big == 1) { METRO_DMA(Dma256x256s2); }
-        METRO_DMA(Dma256x256s4k32);
-    }
-    static const int pro_cfg = env_int("METRO_DMA_PRO", 0);
-    if (blocks256 >= 256 && pro && pro_cfg) {
-        return launch_dma_cfg<Dma128x256s3p, true>(a, in, w, bias, ps, pb, res, out, out_f32, stream);
-    }
+    if (big && d.c_out % 256 == 0 && blocks256 / 2 >= 256) { METRO_DMA(Dma256x256s4k32); }
     if (blocks256 >= 256) { METRO_DMA(Dma128x256s3); }
     METRO_DMA(Dma128x128s4);
 #undef METRO_DMA

@@ -61,3 +61,46 @@ def sharded_forward(forward_fn: Callable[[torch.Tensor], torch.Tensor], images: 
     else:                                   # more ranks than images: learn [J, 3] from one image
         local = forward_fn(images[:1])[:0]
     return all_gather_poses(local, images.shape[0], group)
+
+
+class OverlappedPoseGather:
+    """All-gather of per-rank pose outputs that overlaps with the NEXT batch's forward.
+
+    The collective is latency-bound (<= 15 KB per rank), so it is issued asynchronously (RCCL runs
+    it on its own stream) on double-buffered outputs: `submit(i, local)` starts the gather of step i
+    and only makes the caller's stream wait for the gather of step i-2, whose buffers it is about
+    to reuse.  `result(i)` / `finish()` wait for what is still in flight."""
+
+    def __init__(self, n_local: int, n_joints: int, world: int, device, group=None, depth: int = 2):
+        self.group = group
+        self.depth = depth
+        self.local = [torch.empty((n_local, n_joints, 3), dtype=torch.float32, device=device) for _ in range(depth)]
+        self.gathered = [torch.empty((n_local * world, n_joints, 3), dtype=torch.float32, device=device)
+                         for _ in range(depth)]
+        self.work = [None] * depth
+
+    def local_buffer(self, step: int) -> torch.Tensor:
+        """Output buffer for the forward of `step`; waits (stream-side) for the gather that last used it."""
+        k = step % self.depth
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+        return self.local[k]
+
+    def submit(self, step: int) -> None:
+        k = step % self.depth
+        self.work[k] = dist.all_gather_into_tensor(self.gathered[k], self.local[k], group=self.group,
+                                                   async_op=True)
+
+    def result(self, step: int) -> torch.Tensor:
+        k = step % self.depth
+        if self.work[k] is not None:
+            self.work[k].wait()
+            self.work[k] = None
+        return self.gathered[k]
+
+    def finish(self) -> None:
+        for k in range(self.depth):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from metro_pose3d_amd.dist import all_gather_poses, shard_range, sharded_forward
+from metro_pose3d_amd.dist import OverlappedPoseGather, all_gather_poses, shard_range, sharded_forward
 
 
 def _fake_forward(images):                      # [n, 4, 4, 3] -> [n, 5, 3], per-image only
@@ -31,7 +31,20 @@ def _worker(rank, world, port, n, q):
         got = sharded_forward(_fake_forward, images)
         b, e = shard_range(n, rank, world)
         again = all_gather_poses(_fake_forward(images[b:e]) if e > b else _fake_forward(images[:1])[:0], n)
-        q.put((rank, bool(torch.equal(got, full)), bool(torch.equal(again, full))))
+        ok3 = True
+        if n % world == 0:
+            # overlapped, double-buffered gather over several "steps": every step's result is exact
+            nl = n // world
+            g = OverlappedPoseGather(nl, 5, world, torch.device('cpu'))
+            for step in range(5):
+                buf = g.local_buffer(step)
+                buf.copy_(_fake_forward(images[b:e]) + step)
+                g.submit(step)
+                if step >= 1:
+                    ok3 = ok3 and bool(torch.equal(g.result(step - 1), full + (step - 1)))
+            g.finish()
+            ok3 = ok3 and bool(torch.equal(g.result(4), full + 4))
+        q.put((rank, bool(torch.equal(got, full)), bool(torch.equal(again, full)) and ok3))
     finally:
         dist.destroy_process_group()
 
