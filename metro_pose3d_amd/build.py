@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, 'libmetro_hip.so')
 SOURCES = ['conv_igemm_f16.hip', 'conv_igemm_f16_dma.hip', 'conv3x3_f16_slab.hip', 'conv_igemm_f64acc.hip', 'pool_softargmax.hip', 'plan.cpp']
 HEADERS = ['metro_common.h', os.path.join('..', '..', 'include', 'metro_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-Wall',
-         '-Wno-unused-function']
+         '-Wno-unused-function'] + os.environ.get('METRO_EXTRA_HIPCC_FLAGS', '').split()
 
 
 def _hipcc() -> str:

@@ -222,11 +222,17 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
                 const char* p = bo >= 0 ? sl + bo + ((chunk ^ ((bo >> 8) & 7)) << 4) : zl;
                 bf[j] = *reinterpret_cast<const half8_t*>(p);
             }
+#ifdef METRO_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int i = 0; i < Cfg::WM; ++i)
 #pragma unroll
                 for (int j = 0; j < Cfg::WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+#ifdef METRO_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if constexpr (decltype(issue_slab_c)::value) issue_slab_part(slab_buf ^ 1, kk, kk == 3);
             if constexpr (decltype(issue_w_c)::value) issue_w_part(islot, (TAP + 2) % 9, kk);
         }

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w,
     const float* __restrict__ bias, const half_t* __restrict__ pro_scale,
     const half_t* __restrict__ pro_shift, const half_t* __restrict__ residual,
-    void* __restrict__ out, int out_f32, int tiles_m) {
+    void* __restrict__ out, int out_f32, int tiles_m, void* __restrict__ out2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = Cfg::BK, STAGES = Cfg::STAGES, NW = Cfg::NW;
     constexpr int CPR = Cfg::CPR, RPI = Cfg::RPI;
@@ -288,11 +288,17 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
 #pragma unroll
                 for (int j = 0; j < Cfg::WN; ++j) bf[j] = __builtin_elementwise_max(bf[j] * sc + sh, z);
             }
+#ifdef METRO_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int i = 0; i < Cfg::WM; ++i)
 #pragma unroll
                 for (int j = 0; j < Cfg::WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+#ifdef METRO_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if constexpr (decltype(with_issue)::value) issue_part(kk);
         }
     };
@@ -394,6 +400,12 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     }
 
     // ---- epilogue -----------------------------------------------------------------------
+    // fused pair (ConvSplit): this block's cout tile belongs to exactly one of the two outputs
+    const bool second = a.split > 0 && n0 >= a.split;
+    const int o_c = a.split > 0 ? (second ? a.c_out2 : a.split) : a.c_out;   // channels of the target tensor
+    const int o_n0 = second ? n0 - a.split : n0;                              // tile offset inside it
+    const int o_relu = second ? a.relu2 : a.relu;
+    void* o_ptr = second ? out2 : out;
     if (out_f32) {
         // fp32 output (logits): direct stores, 16 bytes per lane
 #pragma unroll
@@ -438,7 +450,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[i][j][4 * q + e] + bv[e];
-                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (o_relu) v = fmaxf(v, 0.f);
                     hv[e] = (half_t)v;
                 }
                 *reinterpret_cast<half4_t*>(smem + prow * Cfg::OUT_ROW_BYTES + col * 2) = hv;
@@ -447,30 +459,30 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     }
     __syncthreads();
     // 2) row-wise: 16 bytes per lane, (+ prefetched residual), full-line stores
-    half_t* outh = reinterpret_cast<half_t*>(out);
+    half_t* outh = reinterpret_cast<half_t*>(o_ptr);
 #pragma unroll
     for (int it = 0; it < EPI_ITERS; ++it) {
         const int idx = tid + it * Cfg::NT;
         const int prow = idx / CPRO;
         const int ch = idx - prow * CPRO;
         const int m = m0 + prow;
-        const int co = n0 + ch * 8;
-        if (m >= a.m_total || co >= a.c_out) continue;
+        const int co = o_n0 + ch * 8;                // channel inside the target tensor
+        if (m >= a.m_total || co >= o_c) continue;
         uint4 v = *reinterpret_cast<const uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16);
-        if (co + 8 <= a.c_out) {
+        if (co + 8 <= o_c) {
             if (residual != nullptr) {
                 half2_t* x = reinterpret_cast<half2_t*>(&v);
                 const half2_t* r = reinterpret_cast<const half2_t*>(&rres[it]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = x[e] + r[e];    // fp16 Add, like the reference graph
             }
-            *reinterpret_cast<uint4*>(outh + (size_t)m * a.c_out + co) = v;
+            *reinterpret_cast<uint4*>(outh + (size_t)m * o_c + co) = v;
         } else {
             // ragged channel tail (c_out % 8 != 0 never carries a residual: see conv_f16_dma_supported)
             const half8_t x = *reinterpret_cast<const half8_t*>(&v);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (co + e < a.c_out) outh[(size_t)m * a.c_out + co + e] = x[e];
+                if (co + e < o_c) outh[(size_t)m * o_c + co + e] = x[e];
         }
     }
 }
@@ -480,10 +492,16 @@ static int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+static thread_local void* g_out2 = nullptr;   // second output of a fused pair (set by launch_conv_f16_dma)
+
 template <class Cfg, bool PROLOGUE, bool FASTK>
 static int launch_dma_cfg2(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias,
                            const half_t* ps, const half_t* pb, const half_t* res, void* out, int out_f32,
                            hipStream_t stream) {
+    if (a.split > 0 && (a.split % Cfg::TM) != 0) {
+        set_error("conv_igemm_f16_dma: split %d is not a multiple of the %d-wide cout tile", a.split, Cfg::TM);
+        return METRO_ERR_INVALID_ARG;
+    }
     auto kern = conv_igemm_f16_dma_kernel<Cfg, PROLOGUE, FASTK>;
     constexpr int lds = Cfg::MAIN_BYTES + (PROLOGUE ? Cfg::PRO_BYTES : 0);
     static bool attr_set = false;
@@ -499,7 +517,7 @@ static int launch_dma_cfg2(const ConvArgs& a, const half_t* in, const half_t* w,
     const int tiles_m = (a.c_out + Cfg::TM - 1) / Cfg::TM;
     const int tiles_n = (a.m_total + Cfg::TN - 1) / Cfg::TN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::NT), lds, stream, a, in, w, bias, ps, pb,
-                       res, out, out_f32, tiles_m);
+                       res, out, out_f32, tiles_m, g_out2);
     return launch_status("conv_igemm_f16_dma");
 }
 
@@ -531,8 +549,20 @@ bool conv_f16_dma_supported(const MetroConvDesc& d) {
 }
 
 int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_, const float* bias,
-                        const void* ps_, const void* pb_, const void* res_, void* out, hipStream_t stream) {
-    const ConvArgs a = make_conv_args(d);
+                        const void* ps_, const void* pb_, const void* res_, void* out, hipStream_t stream,
+                        const ConvSplit* split) {
+    ConvArgs a = make_conv_args(d);
+    g_out2 = nullptr;
+    if (split != nullptr && split->split > 0) {
+        if (d.has_residual || d.out_dtype != METRO_F16 || split->split + split->c_out2 != d.c_out ||
+            split->split % 256 != 0 || split->c_out2 % 8 != 0) {
+            set_error("conv_igemm_f16_dma: unsupported fused pair (split %d + %d vs c_out %d)", split->split,
+                      split->c_out2, d.c_out);
+            return METRO_ERR_INVALID_ARG;
+        }
+        a.split = split->split; a.c_out2 = split->c_out2; a.relu2 = split->relu2;
+        g_out2 = split->out2;
+    }
     const half_t* in = static_cast<const half_t*>(in_);
     const half_t* w = static_cast<const half_t*>(w_);
     const half_t* ps = static_cast<const half_t*>(ps_);

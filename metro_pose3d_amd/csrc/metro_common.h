@@ -41,7 +41,18 @@ inline int launch_status(const char* what) {
 }
 
 // device-side view of MetroConvDesc plus derived values
+// Two convolutions over the same input fused into one launch: weight/bias rows [0, split) belong
+// to the first output (desc.c_out == split + c_out2 rows in total), rows [split, ...) to `out2`
+// (NHWC with c_out2 channels, its own ReLU flag).  split must be a multiple of the cout tile.
+struct ConvSplit {
+    int split = 0;
+    int c_out2 = 0;
+    int relu2 = 0;
+    void* out2 = nullptr;
+};
+
 struct ConvArgs {
+    int split, c_out2, relu2;   // see ConvSplit (0 = plain convolution)
     int n, h_in, w_in, c_in, in_pix_stride;
     int h_out, w_out, c_out;
     int kh, kw, stride, dil, pad_top, pad_left;
@@ -52,6 +63,7 @@ struct ConvArgs {
 
 inline ConvArgs make_conv_args(const MetroConvDesc& d) {
     ConvArgs a;
+    a.split = 0; a.c_out2 = 0; a.relu2 = 0;
     a.n = d.n; a.h_in = d.h_in; a.w_in = d.w_in; a.c_in = d.c_in; a.in_pix_stride = d.in_pix_stride;
     a.h_out = d.h_out; a.w_out = d.w_out; a.c_out = d.c_out;
     a.kh = d.kh; a.kw = d.kw; a.stride = d.stride; a.dil = d.dilation;
@@ -73,7 +85,7 @@ int launch_conv_f16(const MetroConvDesc& d, const void* in, const void* w, const
 bool conv_f16_dma_supported(const MetroConvDesc& d);
 int launch_conv_f16_dma(const MetroConvDesc& d, const void* in, const void* w, const float* bias,
                         const void* pro_scale, const void* pro_shift, const void* residual, void* out,
-                        hipStream_t stream);
+                        hipStream_t stream, const ConvSplit* split = nullptr);
 // 3x3 stride-1 convs with tap reuse from an LDS-resident activation slab
 bool conv3x3_slab_supported(const MetroConvDesc& d);
 int launch_conv3x3_slab(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out,

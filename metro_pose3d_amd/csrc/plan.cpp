@@ -67,6 +67,8 @@ struct Layer {
     MetroConvDesc cd;     // cd.n is filled per call
     int in_slot, out_slot, res_slot;
     int p_w, p_bias, p_scale, p_shift;
+    // fused pair (projection shortcut + conv1 of the same unit, same pre-activated input):
+    int split, c_out2, relu2, out2_slot;
 };
 
 }  // namespace
@@ -154,10 +156,48 @@ struct Builder {
             L.p_scale = add_param(lname + "/pro_scale", METRO_PARAM_PRO_SCALE, "", pv, wdt, c_in, 1, 1, 1, 1, 1);
             L.p_shift = add_param(lname + "/pro_shift", METRO_PARAM_PRO_SHIFT, "", pv, wdt, c_in, 1, 1, 1, 1, 1);
         }
-        L.in_slot = in_slot; L.out_slot = out_slot; L.res_slot = res_slot;
+        L.in_slot = in_slot; L.out_slot = out_slot; L.res_slot = res_slot; L.out2_slot = S_NONE;
         const int64_t out_es = out_dtype == METRO_F16 ? 2 : out_dtype == METRO_F32 ? 4 : 8;
         need(out_slot, (int64_t)side_out * side_out * c_out * out_es);
         fill_info(L, lname, (double)2.0 * side_out * side_out * c_out * k * k * c_in);
+        p->layers.push_back(L);
+    }
+
+    // Projection shortcut (c_sc outputs, bias, no ReLU) and conv1 (cb outputs, folded BN + ReLU) of a
+    // unit read the same pre-activated tensor: one launch over concatenated weight rows
+    // (reference resnet_v2.py:122-128).  Parameter tensors keep their own names and are laid out
+    // back to back so the kernel sees one [c_sc + cb][c_in] matrix.
+    void add_shortcut_conv1_pair(const std::string& un, const std::string& sc, int in_slot, int side, int c_in,
+                                 int c_sc, int cb, int adt) {
+        Layer L;
+        memset(&L, 0, sizeof(L));
+        L.kind = LK_CONV;
+        MetroConvDesc& cd = L.cd;
+        cd.h_in = cd.w_in = side; cd.c_in = c_in; cd.in_pix_stride = c_in;
+        cd.h_out = cd.w_out = side; cd.c_out = c_sc + cb;
+        cd.kh = cd.kw = 1; cd.stride = 1; cd.dilation = 1;
+        cd.has_prologue = 1; cd.relu = 0; cd.has_residual = 0; cd.res_stride = 1;
+        cd.out_dtype = adt; cd.in_dtype = adt;
+        const std::string pre = root + "/" + sc + "/preact";
+        L.p_w = add_param(un + "/shortcut/W", METRO_PARAM_CONV_W, root + "/" + sc + "/shortcut", "", METRO_F16, c_sc, 1, 1, c_in, 1, c_in);
+        const int w2 = add_param(un + "/conv1/W", METRO_PARAM_CONV_W, root + "/" + sc + "/conv1", root + "/" + sc + "/conv1/BatchNorm",
+                                 METRO_F16, cb, 1, 1, c_in, 1, c_in);
+        L.p_bias = add_param(un + "/shortcut/bias", METRO_PARAM_BIAS, root + "/" + sc + "/shortcut", "", METRO_F32, c_sc, 1, 1, 1, 1, 1);
+        const int b2 = add_param(un + "/conv1/bias", METRO_PARAM_BIAS, root + "/" + sc + "/conv1", root + "/" + sc + "/conv1/BatchNorm",
+                                 METRO_F32, cb, 1, 1, 1, 1, 1);
+        // contiguity (sizes are multiples of the 256-byte blob alignment for c_sc % 256 == 0, c_in % 64 == 0)
+        if (p->params[w2].offset != p->params[L.p_w].offset + p->params[L.p_w].bytes ||
+            p->params[b2].offset != p->params[L.p_bias].offset + p->params[L.p_bias].bytes) {
+            set_error("internal: fused pair parameters are not contiguous");
+        }
+        L.p_scale = add_param(un + "/shortcut/pro_scale", METRO_PARAM_PRO_SCALE, "", pre, METRO_F16, c_in, 1, 1, 1, 1, 1);
+        L.p_shift = add_param(un + "/shortcut/pro_shift", METRO_PARAM_PRO_SHIFT, "", pre, METRO_F16, c_in, 1, 1, 1, 1, 1);
+        L.in_slot = in_slot; L.out_slot = S_SC; L.res_slot = S_NONE;
+        L.split = c_sc; L.c_out2 = cb; L.relu2 = 1; L.out2_slot = S_T1;
+        need(S_SC, (int64_t)side * side * c_sc * 2);
+        need(S_T1, (int64_t)side * side * cb * 2);
+        fill_info(L, un + "/shortcut+conv1", 2.0 * side * side * (double)(c_sc + cb) * c_in);
+        L.info.c_out = c_sc;      // the primary output tensor (S_SC) has c_sc channels
         p->layers.push_back(L);
     }
 
@@ -285,14 +325,22 @@ int build_plan(MetroPlan* p) {
             const int shift = (unit_centered && s == 2) ? 1 : 0;             // resnet_v2.py:113-115
             const int nxt = cur == S_X0 ? S_X1 : S_X0;
             const bool project = cur_c != cout;                              // resnet_v2.py:120-125
-            if (project) {
-                // conv1x1(shift(preact), stride s) + bias: input pixel = shift + s*ho
-                B.add_conv(un + "/shortcut", sc + "/shortcut", "", sc + "/preact", cur, S_SC, S_NONE,
-                           cur_side, cur_c, side_out, cout, 1, s, 1, -shift, false, 0, 1, 0, adt, adt);
+            // measured on MI355X (batch 64): pays when conv1 fills whole 128-cout tiles and the pair is not huge
+            // (block2/block3 of ResNet-50/101: -9 / -7 us); block1 (cb = 64: a half-empty tile) and block4 lose
+            const bool fuse_pair = fast && project && s == 1 && cout % 256 == 0 && cur_c % 64 == 0 &&
+                                   cb % 128 == 0 && cout <= 1024;
+            if (fuse_pair) {
+                B.add_shortcut_conv1_pair(un, sc, cur, cur_side, cur_c, cout, cb, adt);
+            } else {
+                if (project) {
+                    // conv1x1(shift(preact), stride s) + bias: input pixel = shift + s*ho
+                    B.add_conv(un + "/shortcut", sc + "/shortcut", "", sc + "/preact", cur, S_SC, S_NONE,
+                               cur_side, cur_c, side_out, cout, 1, s, 1, -shift, false, 0, 1, 0, adt, adt);
+                }
+                // conv1: 1x1 on preact, BN+ReLU folded (resnet_v2.py:127-128)
+                B.add_conv(un + "/conv1", sc + "/conv1", sc + "/conv1/BatchNorm", sc + "/preact", cur, S_T1,
+                           S_NONE, cur_side, cur_c, cur_side, cb, 1, 1, 1, 0, true, 0, 1, 0, adt, adt);
             }
-            // conv1: 1x1 on preact, BN+ReLU folded (resnet_v2.py:127-128)
-            B.add_conv(un + "/conv1", sc + "/conv1", sc + "/conv1/BatchNorm", sc + "/preact", cur, S_T1,
-                       S_NONE, cur_side, cur_c, cur_side, cb, 1, 1, 1, 0, true, 0, 1, 0, adt, adt);
             // conv2: conv2d_same 3x3 (resnet_utils.py:82-135)
             const int k_eff = 3 + 2 * (r - 1);
             const int pad_beg = (s == 1 || unit_centered) ? tf_same_pad_beg(cur_side, k_eff, s)
@@ -342,7 +390,7 @@ int build_plan(MetroPlan* p) {
     for (Layer& L : p->layers) {
         L.info.out_offset = L.out_slot >= 0 ? p->slot_offset[L.out_slot] : -1;
         const int64_t es = L.cd.out_dtype == METRO_F16 ? 2 : L.cd.out_dtype == METRO_F32 ? 4 : 8;
-        L.info.out_bytes_per_image = (int64_t)L.cd.h_out * L.cd.w_out * L.cd.c_out * es;
+        L.info.out_bytes_per_image = (int64_t)L.cd.h_out * L.cd.w_out * (L.split > 0 ? L.split : L.cd.c_out) * es;
     }
     return METRO_OK;
 }
@@ -384,7 +432,12 @@ int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_
             case LK_CONV: {
                 MetroConvDesc cd = L.cd;
                 cd.n = n;
-                if (p->fast)
+                if (p->fast && L.split > 0) {
+                    ConvSplit sp;
+                    sp.split = L.split; sp.c_out2 = L.c_out2; sp.relu2 = L.relu2; sp.out2 = slot_ptr(L.out2_slot);
+                    st = launch_conv_f16_dma(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
+                                             prm(L.p_scale), prm(L.p_shift), nullptr, slot_ptr(L.out_slot), stream, &sp);
+                } else if (p->fast)
                     st = launch_conv_f16(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
                                          prm(L.p_scale), prm(L.p_shift), slot_ptr(L.res_slot),
                                          slot_ptr(L.out_slot), stream);

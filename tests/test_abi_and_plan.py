@@ -65,13 +65,24 @@ def test_plan_flops_match_published_accounting(key):
 @pytest.mark.parametrize('arch', [50, 101])
 @pytest.mark.parametrize('stride', [32, 16, 8, 4])
 @pytest.mark.parametrize('centered', [True, False])
-def test_planner_agrees_with_oracle_schedule(arch, stride, centered):
+@pytest.mark.parametrize('prec', ['f16', 'f64'])
+def test_planner_agrees_with_oracle_schedule(arch, stride, centered, prec):
     spec = ModelSpec(arch, stride, 'h36m', centered_stride=centered)
     units = schedule(OracleSpec(arch=arch, stride=stride, centered_stride=centered))
-    layers = {li.name.decode(): li for li in Engine(spec, None, 'f16', max_batch=1).layer_infos()}
+    layers = {li.name.decode(): li for li in Engine(spec, None, prec, max_batch=1).layer_infos()}
     assert layers['conv1'].h_out == 128 and layers['pool1'].h_out == 64
     for u in units:
-        c1, c2, c3 = (layers[f'{u.name}/conv{i}'] for i in (1, 2, 3))
+        c2, c3 = (layers[f'{u.name}/conv{i}'] for i in (2, 3))
+        if f'{u.name}/shortcut+conv1' in layers:
+            # fp16 plans fuse the projection shortcut and conv1 of a unit (same pre-activated input)
+            pair = layers[f'{u.name}/shortcut+conv1']
+            assert u.c_in != u.c_out and u.stride == 1 and u.c_out % 256 == 0
+            assert (pair.c_in, pair.c_out, pair.h_in, pair.has_prologue, pair.kh) == (u.c_in, u.c_out, u.side_in, 1, 1)
+            assert abs(pair.flops_per_image - 2.0 * u.side_in ** 2 * u.c_in * (u.c_out + u.c_bott)) < 1
+            assert (c3.c_out, c3.has_residual, c3.res_stride, c3.res_offset) == (u.c_out, 1, 1, 0)
+            assert (c2.kh, c2.stride, c2.dilation, c2.c_out) == (3, u.stride, u.rate, u.c_bott)
+            continue
+        c1 = layers[f'{u.name}/conv1']
         assert (c1.c_in, c1.c_out, c1.h_in, c1.has_prologue, c1.relu) == (u.c_in, u.c_bott, u.side_in, 1, 1)
         assert (c2.kh, c2.stride, c2.dilation, c2.h_in, c2.h_out, c2.c_out) == (3, u.stride, u.rate, u.side_in, u.side_out, u.c_bott)
         k_eff = 3 + 2 * (u.rate - 1)
@@ -87,7 +98,8 @@ def test_planner_agrees_with_oracle_schedule(arch, stride, centered):
             assert (sc.stride, sc.pad_top, sc.has_prologue, sc.c_out) == (u.stride, -shift, 1, u.c_out)
             assert (c3.res_stride, c3.res_offset) == (1, 0)
     lg = layers['logits']
-    assert (lg.h_out, lg.c_out, lg.has_prologue, lg.out_dtype) == (256 // stride, 136, 1, _lib.METRO_F32)
+    assert (lg.h_out, lg.c_out, lg.has_prologue) == (256 // stride, 136, 1)
+    assert lg.out_dtype == (_lib.METRO_F32 if prec == 'f16' else _lib.METRO_F64)
 
 
 def test_plan_rejects_bad_specs(lib):
