@@ -48,8 +48,9 @@ __device__ __forceinline__ void slab_wait_barrier() {
 }
 
 // WM: 32-row cout tiles per wave (TM = WAVES_M*WM*32); pixels: TN = 256 = WAVES_N * WN * 32
-template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int SLAB_ROWS_>
+template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int SLAB_ROWS_, int SLAB_BUFS_ = 2>
 struct SlabCfg {
+    static constexpr int SLAB_BUFS = SLAB_BUFS_;             // 1: single-chunk layers (c_in == 64): half the LDS, 2 blocks/CU
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM = WM_, WN = WN_;
     static constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
     static constexpr int TM = WAVES_M * WM * 32, TN = WAVES_N * WN * 32;
@@ -57,16 +58,17 @@ struct SlabCfg {
     static constexpr int SI = SLAB_ROWS / (8 * NW);          // slab DMA instructions per wave per chunk
     static constexpr int WI = TM / (8 * NW);                 // weight DMA instructions per wave per step
     static constexpr int SLAB_BYTES = SLAB_ROWS * 128;
-    static constexpr int ZERO_OFF = 2 * SLAB_BYTES;          // 256-byte zero area behind the slabs
+    static constexpr int ZERO_OFF = SLAB_BUFS * SLAB_BYTES;  // 256-byte zero area behind the slab(s)
     static constexpr int W_OFF = ZERO_OFF + 256;
     static constexpr int W_STAGE_BYTES = TM * 128;
     static constexpr int W_STAGES = 3;
-    static constexpr int LDS_BYTES = W_OFF + W_STAGES * W_STAGE_BYTES;
+    static constexpr int RAW_BYTES = W_OFF + W_STAGES * W_STAGE_BYTES;
     static constexpr int OUT_ROW_BYTES = TM * 2 + 16;
     static constexpr int OUT_BYTES = TN * OUT_ROW_BYTES;
+    static constexpr int LDS_BYTES = RAW_BYTES > OUT_BYTES ? RAW_BYTES : OUT_BYTES;
     static_assert(TN == 256, "slab kernel tiles 256 pixels");
     static_assert(SLAB_ROWS % (8 * NW) == 0 && TM % (8 * NW) == 0, "loader mismatch");
-    static_assert(OUT_BYTES <= 2 * SLAB_BYTES, "epilogue tile must fit in the slab buffers");
+    // the epilogue tile overlays slabs + zero area + weight ring (all idle by then)
 };
 
 template <class Cfg>
@@ -264,8 +266,8 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
         step(std::integral_constant<int, 8>{}, F{}, F{}, std::integral_constant<int, 0>{}, slab_buf, 2);
     };
     (void)I; (void)nq;
-    for (int c = 0; c + 1 < kc; ++c) chunk_main(c & 1);
-    chunk_last((kc - 1) & 1);
+    for (int c = 0; c + 1 < kc; ++c) chunk_main(c & 1);      // (kc > 1 requires SLAB_BUFS == 2: launcher)
+    chunk_last(Cfg::SLAB_BUFS == 2 ? (kc - 1) & 1 : 0);
 
     // ---- epilogue: (+bias, ReLU) -> LDS [pixel][cout] -> full-line stores ------------------------
     __syncthreads();
@@ -337,7 +339,9 @@ using Slab128r320 = SlabCfg<2, 4, 2, 2, 320>;   // 128 cout x 256 px, halo <= 32
 using Slab128r384 = SlabCfg<2, 4, 2, 2, 384>;   // halo <= 64:  96 + 48 KiB
 using Slab64r320 = SlabCfg<1, 8, 2, 1, 320>;    //  64 cout x 256 px
 using Slab64r384 = SlabCfg<1, 8, 2, 1, 384>;
-using Slab64r512 = SlabCfg<1, 8, 2, 1, 512>;    // halo <= 128 (64-wide maps, rate 1): 128 + 24 KiB
+using Slab64r512 = SlabCfg<1, 8, 2, 1, 512>;    // halo <= 128: 128 + 24 KiB
+using Slab64r384b1 = SlabCfg<1, 8, 2, 1, 384, 1>;  // single chunk (c_in == 64), halo <= 64: 48 + 24 KiB -> 2 blocks / CU
+using Slab64r320b1 = SlabCfg<1, 8, 2, 1, 320, 1>;
 
 bool conv3x3_slab_supported(const MetroConvDesc& d) {
     static const int enabled = [] { const char* e = getenv("METRO_CONV_SLAB"); return e ? atoi(e) : 1; }();
@@ -347,7 +351,10 @@ bool conv3x3_slab_supported(const MetroConvDesc& d) {
           d.out_dtype == METRO_F16 && d.in_dtype == METRO_F16 && d.in_pix_stride == d.c_in &&
           d.c_in % 64 == 0 && d.c_out % 8 == 0))
         return false;
-    const int halo = d.dilation * d.w_out + d.dilation;
+    // tiles are 256 consecutive pixels starting at column 0 (256 % W == 0): a tap (dr, ds<0) of a pixel
+    // at x < dil is outside the image, so the slab needs dil*W rows of halo, not dil*W + dil
+    if (256 % d.w_out != 0) return false;
+    const int halo = d.dilation * d.w_out;
     const long m = (long)d.n * d.h_out * d.w_out;
     if (m < 256) return false;
     if (d.c_out <= 64) return halo <= 128;
@@ -360,10 +367,12 @@ int launch_conv3x3_slab(const MetroConvDesc& d, const void* in_, const void* w_,
     const half_t* in = static_cast<const half_t*>(in_);
     const half_t* w = static_cast<const half_t*>(w_);
     half_t* out = static_cast<half_t*>(out_);
-    const int halo = d.dilation * d.w_out + d.dilation;
+    const int halo = d.dilation * d.w_out;
     // 64-cout tiles when 128-cout tiles would leave CUs without a block (256 CUs)
     const long blocks128 = (long)((d.c_out + 127) / 128) * ((a.m_total + 255) / 256);
     if (d.c_out <= 64 || blocks128 < 256) {
+        if (d.c_in == 64 && halo <= 32) return launch_slab_cfg<Slab64r320b1>(a, in, w, bias, out, halo, stream);
+        if (d.c_in == 64 && halo <= 64) return launch_slab_cfg<Slab64r384b1>(a, in, w, bias, out, halo, stream);
         if (halo <= 32) return launch_slab_cfg<Slab64r320>(a, in, w, bias, out, halo, stream);
         if (halo <= 64) return launch_slab_cfg<Slab64r384>(a, in, w, bias, out, halo, stream);
         return launch_slab_cfg<Slab64r512>(a, in, w, bias, out, halo, stream);
