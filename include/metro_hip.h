@@ -172,6 +172,15 @@ int  metro_conv_f64acc(const MetroConvDesc* d, const void* d_in, const double* d
  * pad-3 of reference resnet_utils.py:125-135 materialised once; channel 3 is zero). */
 int  metro_prep_input_f16(const float* d_images, int32_t n, int32_t side, void* d_out, void* stream);
 
+/* Crop pre-processing, the step before the path: n crops of one uint8
+ * HWC RGB frame [h, w, 3] (row_stride bytes per row), crop i sampled through the 3x3 homography
+ * d_homographies[i] (row-major fp32, maps OUTPUT pixel (x, y, 1) to SOURCE pixel coordinates) with
+ * bilinear interpolation and constant-0 border, then /255 and clip -- reference
+ * src/cameralib.py:406-429 (reproject_image_fast -> cv2.remap) + src/improc.py:56-61 (normalize01).
+ * d_out: fp32 NHWC [n, side, side, 3], exactly the input contract of metro_forward. */
+int  metro_warp_crop_u8(const uint8_t* d_image, int32_t h, int32_t w, int32_t row_stride,
+                        const float* d_homographies, int32_t n, int32_t side, float* d_out, void* stream);
+
 /* 3x3 stride-2 max-pool over a ZERO-padded (1,1) input (reference resnet_utils.py:177-185).
  * dtype METRO_F16 / METRO_F32 / METRO_F64; c % 8 == 0 (f16), c % 4 == 0 (f32), c % 2 == 0 (f64). */
 int  metro_maxpool3x3s2_zeropad(const void* d_in, void* d_out, int32_t n, int32_t h_in,

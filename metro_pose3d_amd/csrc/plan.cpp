@@ -590,6 +590,13 @@ int metro_prep_input_f16(const float* d_images, int32_t n, int32_t side, void* d
     return launch_prep_input_f16(d_images, n, side, d_out, static_cast<hipStream_t>(stream));
 }
 
+int metro_warp_crop_u8(const uint8_t* d_image, int32_t h, int32_t w, int32_t row_stride, const float* d_homographies,
+                       int32_t n, int32_t side, float* d_out, void* stream) {
+    METRO_CHECK_ARG(d_image && d_homographies && d_out, "warp_crop_u8: NULL pointer");
+    METRO_CHECK_ARG(h > 0 && w > 0 && n > 0 && side > 0 && row_stride >= 3 * w, "warp_crop_u8: bad geometry (h %d w %d stride %d n %d side %d)", h, w, row_stride, n, side);
+    return launch_warp_crop_u8(d_image, h, w, row_stride, d_homographies, d_out, n, side, static_cast<hipStream_t>(stream));
+}
+
 int metro_maxpool3x3s2_zeropad(const void* d_in, void* d_out, int32_t n, int32_t h_in, int32_t w_in,
                                int32_t c, int32_t dtype, void* stream) {
     METRO_CHECK_ARG(d_in && d_out && n > 0 && h_in > 0 && w_in > 0 && c > 0, "maxpool: bad argument");

@@ -45,6 +45,62 @@ int launch_prep_input_f16(const float* images, int n, int side, void* out, hipSt
 }
 
 // ---------------------------------------------------------------------------------------------
+// Crop pre-processing (the step BEFORE the path): for every output
+// pixel (x, y) of crop i, source coords = H_i * [x, y, 1] (fp32, perspective divide), bilinear
+// sample of the uint8 HWC frame with constant-0 border, then /255 and clip to [-1, 1]:
+// reference src/cameralib.py:406-429 (reproject_image_fast: homography -> cv2.remap INTER_LINEAR,
+// BORDER_CONSTANT 0) followed by src/improc.py:56-61 (normalize01).  OpenCV's remap interpolates in
+// fixed point (coordinates rounded to 1/32 px, 15-bit weights); this kernel interpolates in fp32,
+// so it can differ from cv2 by up to ~1 uint8 LSB (0.004) -- stated in DESIGN.md, not hidden.
+// One thread per output pixel (3 channels), 12-byte stores.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_crop_u8_kernel(const unsigned char* __restrict__ img, int h, int w,
+                                                           int row_stride, const float* __restrict__ homs,
+                                                           float* __restrict__ out, int n, int side) {
+    const long total = (long)n * side * side;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(p % side);
+        const long t = p / side;
+        const int y = (int)(t % side);
+        const int i = (int)(t / side);
+        const float* H = homs + i * 9;
+        const float fx = (float)x, fy = (float)y;
+        const float cx = H[0] * fx + H[1] * fy + H[2];
+        const float cy = H[3] * fx + H[4] * fy + H[5];
+        const float cw = H[6] * fx + H[7] * fy + H[8];
+        const float u = cx / cw, v = cy / cw;
+        const float uf = floorf(u), vf = floorf(v);
+        const float a = u - uf, b = v - vf;
+        const int x0 = (int)uf, y0 = (int)vf;
+        float acc[3] = {0.f, 0.f, 0.f};
+        // NaN / huge coordinates fail every bounds test and yield the border value 0
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int xx = x0 + dx, yy = y0 + dy;
+                const float wgt = (dx ? a : 1.f - a) * (dy ? b : 1.f - b);
+                if ((unsigned)xx < (unsigned)w && (unsigned)yy < (unsigned)h && u == u && v == v) {
+                    const unsigned char* s = img + (size_t)yy * row_stride + (size_t)xx * 3;
+                    acc[0] += wgt * (float)s[0]; acc[1] += wgt * (float)s[1]; acc[2] += wgt * (float)s[2];
+                }
+            }
+        }
+        float* o = out + p * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = fminf(fmaxf(acc[c] / 255.f, -1.f), 1.f);
+    }
+}
+
+int launch_warp_crop_u8(const unsigned char* img, int h, int w, int row_stride, const float* homs, float* out,
+                        int n, int side, hipStream_t stream) {
+    const long total = (long)n * side * side;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(warp_crop_u8_kernel, dim3(blocks), dim3(256), 0, stream, img, h, w, row_stride, homs, out, n, side);
+    return launch_status("warp_crop_u8");
+}
+
+// ---------------------------------------------------------------------------------------------
 // 3x3 stride-2 max-pool over an input ZERO-padded by (1,1) (reference resnet_utils.py:177-185:
 // array_ops.pad then VALID pooling -> the pad value 0 takes part in the max).
 // One thread per (output pixel, 16-byte channel chunk).
