@@ -195,6 +195,16 @@ int64_t metro_softargmax_scratch_bytes(int32_t n, int32_t side, int32_t n_joints
 int  metro_softargmax(const void* d_logits, int32_t n, const MetroSpec* spec, int32_t precise,
                       void* d_partials, float* d_poses_out, void* stream);
 
+/* Evaluation metrics, the step after the path (reference
+ * src/main.py:339-359): per (pose, joint) root-relative distance in mm before and after rigid
+ * alignment with scale (Procrustes without reflection: src/util3d.py:139-159,
+ * src/eval/procrustes.py:6-107), and per-joint sums over the valid entries of
+ * {count, dist, dist_aligned, max(0, 1 - dist/threshold), dist <= threshold} -> d_sums[J][5] (fp64).
+ * d_pred / d_true: fp32 [n, J, 3] (root = last joint); d_valid: uint8 [n, J]. */
+int  metro_eval_metrics(const float* d_pred, const float* d_true, const uint8_t* d_valid, int32_t n,
+                        int32_t n_joints, float threshold_mm, float* d_dist, float* d_dist_aligned,
+                        double* d_sums, void* stream);
+
 const char* metro_last_error(void);
 int32_t metro_abi_version(void);
 

@@ -73,6 +73,7 @@ SIGNATURES = {
     'metro_conv_f64acc': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_prep_input_f16': (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     'metro_warp_crop_u8': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
+    'metro_eval_metrics': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P]),
     'metro_maxpool3x3s2_zeropad': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                              C.c_int32, _P]),
     'metro_softargmax_scratch_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

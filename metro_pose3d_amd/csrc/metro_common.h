@@ -96,6 +96,8 @@ int launch_conv_f64acc(const MetroConvDesc& d, const void* in, const double* w, 
 int launch_prep_input_f16(const float* images, int n, int side, void* out, hipStream_t stream);
 int launch_warp_crop_u8(const unsigned char* img, int h, int w, int row_stride, const float* homs, float* out,
                         int n, int side, hipStream_t stream);
+int launch_eval_metrics(const float* pred, const float* truth, const unsigned char* valid, int n, int nj,
+                        float threshold, float* dist, float* dist_pa, double* sums, hipStream_t stream);
 int launch_maxpool(const void* in, void* out, int n, int h_in, int w_in, int c, int dtype,
                    hipStream_t stream);
 

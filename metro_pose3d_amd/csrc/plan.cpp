@@ -597,6 +597,14 @@ int metro_warp_crop_u8(const uint8_t* d_image, int32_t h, int32_t w, int32_t row
     return launch_warp_crop_u8(d_image, h, w, row_stride, d_homographies, d_out, n, side, static_cast<hipStream_t>(stream));
 }
 
+int metro_eval_metrics(const float* d_pred, const float* d_true, const uint8_t* d_valid, int32_t n, int32_t n_joints,
+                       float threshold_mm, float* d_dist, float* d_dist_aligned, double* d_sums, void* stream) {
+    METRO_CHECK_ARG(d_pred && d_true && d_valid && d_dist && d_dist_aligned && d_sums, "eval_metrics: NULL pointer");
+    METRO_CHECK_ARG(n > 0 && n_joints >= 3 && n_joints <= 1024 && threshold_mm > 0.f, "eval_metrics: bad sizes (n %d, joints %d)", n, n_joints);
+    return launch_eval_metrics(d_pred, d_true, d_valid, n, n_joints, threshold_mm, d_dist, d_dist_aligned, d_sums,
+                               static_cast<hipStream_t>(stream));
+}
+
 int metro_maxpool3x3s2_zeropad(const void* d_in, void* d_out, int32_t n, int32_t h_in, int32_t w_in,
                                int32_t c, int32_t dtype, void* stream) {
     METRO_CHECK_ARG(d_in && d_out && n > 0 && h_in > 0 && w_in > 0 && c > 0, "maxpool: bad argument");
