@@ -67,7 +67,7 @@ def cpu_baseline(spec, params, seconds: float, crops: int):
     with torch.no_grad():
         # pick the thread count the host actually runs this graph fastest with (1 crop each)
         best = (float('inf'), 1)
-        for threads in sorted({t for t in (8, 16, 32, 64, avail) if t <= avail}):
+        for threads in sorted({t for t in (8, 16, 32, 64, min(avail, 96)) if t <= avail}):
             torch.set_num_threads(threads)
             OF.forward(ospec, params, images[:1], torch.float32)    # warm-up (allocators, oneDNN)
             t0 = time.perf_counter()
