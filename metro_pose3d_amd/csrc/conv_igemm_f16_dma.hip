@@ -53,6 +53,7 @@ struct DmaCfg {
     static constexpr int PRO_BYTES = 2 * 2048 * 2;        // scale + shift, c_in <= 2048
     static_assert(TM % (RPI * NW) == 0 && TN % (RPI * NW) == 0, "tile/loader mismatch");
     static_assert(BK == 64 || BK == 32, "BK must be 32 or 64");
+    static_assert(STAGES >= 1 && STAGES <= 6, "ring depth 1..6");
 };
 
 // chunk swizzle so that ds_read_b128 of 32 rows x one chunk hits 16 distinct 16-byte slots per
@@ -384,15 +385,24 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
         // drain: nothing left to issue, the in-flight count runs down (residual loads ride along)
         if (has_res) prefetch_residual();
         for (int k = n_main < 0 ? 0 : n_main; k < nk; ++k) {
-            const int ahead = nk - 1 - k;
+            int ahead = nk - 1 - k;                      // younger steps still allowed in flight
+            if (ahead > STAGES - 2) ahead = STAGES - 2;
             if (has_res) {
-                if (STAGES >= 4 && ahead >= 2) wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS + EPI_ITERS>();
-                else if (STAGES >= 3 && ahead >= 1) wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS + EPI_ITERS>();
-                else wait_vm_and_barrier<EPI_ITERS>();
+                switch (ahead) {
+                    case 4: wait_vm_and_barrier<(STAGES >= 6 ? 4 : 0) * Cfg::LPS + EPI_ITERS>(); break;
+                    case 3: wait_vm_and_barrier<(STAGES >= 5 ? 3 : 0) * Cfg::LPS + EPI_ITERS>(); break;
+                    case 2: wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS + EPI_ITERS>(); break;
+                    case 1: wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS + EPI_ITERS>(); break;
+                    default: wait_vm_and_barrier<EPI_ITERS>(); break;
+                }
             } else {
-                if (STAGES >= 4 && ahead >= 2) wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS>();
-                else if (STAGES >= 3 && ahead >= 1) wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS>();
-                else wait_vm_and_barrier<0>();
+                switch (ahead) {
+                    case 4: wait_vm_and_barrier<(STAGES >= 6 ? 4 : 0) * Cfg::LPS>(); break;
+                    case 3: wait_vm_and_barrier<(STAGES >= 5 ? 3 : 0) * Cfg::LPS>(); break;
+                    case 2: wait_vm_and_barrier<(STAGES >= 4 ? 2 : 0) * Cfg::LPS>(); break;
+                    case 1: wait_vm_and_barrier<(STAGES >= 3 ? 1 : 0) * Cfg::LPS>(); break;
+                    default: wait_vm_and_barrier<0>(); break;
+                }
             }
             compute_step(cbuf, cc0, No{});
             advance();
