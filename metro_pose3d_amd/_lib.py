@@ -66,6 +66,7 @@ SIGNATURES = {
     'metro_plan_layer_info': (C.c_int, [_P, C.c_int32, C.POINTER(MetroLayerInfo)]),
     'metro_plan_flops_per_image': (C.c_double, [_P]),
     'metro_plan_bind_params': (C.c_int, [_P, _P]),
+    'metro_plan_set_graph_max_batch': (C.c_int, [_P, C.c_int32]),
     'metro_forward': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
     'metro_forward_upto': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32]),
     'metro_forward_timed': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_float)]),

@@ -73,7 +73,21 @@ struct Layer {
 
 }  // namespace
 
+// A captured forward: valid for exactly this (batch, buffers, stream) tuple.
+struct GraphEntry {
+    int n;
+    const void* images;
+    const void* poses;
+    const void* ws;
+    hipStream_t stream;
+    hipGraphExec_t exec;
+    int eager_runs;          // the first call for a key runs eagerly (lazy one-time setup must not be captured)
+};
+
 struct MetroPlan {
+    std::vector<GraphEntry> graphs;
+    hipStream_t cap_stream = nullptr;   // private stream used only to CAPTURE (the legacy null stream cannot capture)
+    int graph_max_batch = 0;   // forwards with n <= this replay a captured hipGraph (0 = always eager)
     MetroSpec spec;
     int max_batch;
     bool fast;
@@ -512,7 +526,14 @@ int metro_plan_create(const MetroSpec* spec, int32_t max_batch, MetroPlan** out_
     return METRO_OK;
 }
 
-int metro_plan_destroy(MetroPlan* plan) { delete plan; return METRO_OK; }
+int metro_plan_destroy(MetroPlan* plan) {
+    if (plan)
+        for (GraphEntry& g : plan->graphs)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (plan && plan->cap_stream) (void)hipStreamDestroy(plan->cap_stream);
+    delete plan;
+    return METRO_OK;
+}
 int64_t metro_plan_workspace_bytes(const MetroPlan* plan) { return plan ? plan->workspace_bytes : -1; }
 int64_t metro_plan_param_bytes(const MetroPlan* plan) { return plan ? plan->param_bytes : -1; }
 int32_t metro_plan_num_params(const MetroPlan* plan) { return plan ? (int32_t)plan->params.size() : -1; }
@@ -538,9 +559,48 @@ int metro_plan_bind_params(MetroPlan* plan, const void* d_param_blob) {
     return METRO_OK;
 }
 
+int metro_plan_set_graph_max_batch(MetroPlan* plan, int32_t max_batch_for_graphs) {
+    METRO_CHECK_ARG(plan != nullptr && max_batch_for_graphs >= 0, "metro_plan_set_graph_max_batch: bad argument");
+    plan->graph_max_batch = max_batch_for_graphs;
+    return METRO_OK;
+}
+
 int metro_forward(MetroPlan* plan, const float* d_images_nhwc, int32_t n, float* d_poses_out,
-                  void* d_workspace, void* stream) {
-    return run_layers(plan, d_images_nhwc, n, d_poses_out, d_workspace, static_cast<hipStream_t>(stream), -1, nullptr);
+                  void* d_workspace, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (plan == nullptr || n > plan->graph_max_batch || n < 1)
+        return run_layers(plan, d_images_nhwc, n, d_poses_out, d_workspace, stream, -1, nullptr);
+    // small batches are launch-latency bound (57 dependent launches): replay a captured hipGraph
+    GraphEntry* hit = nullptr;
+    for (GraphEntry& g : plan->graphs)
+        if (g.n == n && g.images == d_images_nhwc && g.poses == d_poses_out && g.ws == d_workspace)
+            hit = &g;
+    if (hit == nullptr) {
+        if (plan->graphs.size() >= 16) {            // bounded cache: drop the oldest capture
+            if (plan->graphs.front().exec) (void)hipGraphExecDestroy(plan->graphs.front().exec);
+            plan->graphs.erase(plan->graphs.begin());
+        }
+        plan->graphs.push_back(GraphEntry{n, d_images_nhwc, d_poses_out, d_workspace, stream, nullptr, 0});
+        hit = &plan->graphs.back();
+    }
+    if (hit->exec == nullptr) {
+        if (hit->eager_runs == 0) {                  // first sight of this key: plain launches (sets kernel attributes)
+            hit->eager_runs = 1;
+            return run_layers(plan, d_images_nhwc, n, d_poses_out, d_workspace, stream, -1, nullptr);
+        }
+        hipGraph_t graph = nullptr;
+        if (plan->cap_stream == nullptr) METRO_HIP_CHECK(hipStreamCreateWithFlags(&plan->cap_stream, hipStreamNonBlocking));
+        METRO_HIP_CHECK(hipStreamBeginCapture(plan->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int st = run_layers(plan, d_images_nhwc, n, d_poses_out, d_workspace, plan->cap_stream, -1, nullptr);
+        const hipError_t e = hipStreamEndCapture(plan->cap_stream, &graph);
+        if (st != METRO_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+        if (e != hipSuccess) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return METRO_ERR_HIP; }
+        const hipError_t ei = hipGraphInstantiate(&hit->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) { hit->exec = nullptr; set_error("hipGraphInstantiate: %s", hipGetErrorString(ei)); return METRO_ERR_HIP; }
+    }
+    METRO_HIP_CHECK(hipGraphLaunch(hit->exec, stream));
+    return METRO_OK;
 }
 
 int metro_forward_upto(MetroPlan* plan, const float* d_images_nhwc, int32_t n, float* d_poses_out,

@@ -77,6 +77,12 @@ class Engine:
         check(self.lib.metro_plan_create(C.byref(cspec), self.max_batch, C.byref(self._plan)),
               'metro_plan_create')
         self.cspec = cspec
+        # hipGraph replay of the forward for batches <= METRO_HIPGRAPH_MAX_BATCH (default 0 = off:
+        # measured on MI355X, batch 1..8 is bound by per-kernel dependency latency on the GPU, not by
+        # host launches -- 0.661 ms eager vs 0.669 ms replayed, tools/graph_probe.py)
+        import os
+        gmax = int(os.environ.get('METRO_HIPGRAPH_MAX_BATCH', '0'))
+        check(self.lib.metro_plan_set_graph_max_batch(self._plan, gmax), 'metro_plan_set_graph_max_batch')
         self.device = None
         self._blob = None
         self._ws = None

@@ -137,3 +137,19 @@ def test_race_screen_repeated_runs_are_bit_identical(cuda):
         a = eng.forward_upto(x, li)
         for _ in range(5):
             assert torch.equal(eng.forward_upto(x, li), a), f'layer {li} not deterministic'
+
+
+def test_hipgraph_replay_is_bit_identical(cuda, monkeypatch):
+    """metro_plan_set_graph_max_batch: a captured forward replays to the same bits as plain launches."""
+    spec = ModelSpec(50, 32, 'h36m', base_width=16)
+    params, images = _setup(spec, 2)
+    x = torch.from_numpy(images).to(cuda)
+    monkeypatch.setenv('METRO_HIPGRAPH_MAX_BATCH', '0')
+    ref = Engine(spec, params, 'f16', max_batch=2, device=cuda).forward(x).clone()
+    monkeypatch.setenv('METRO_HIPGRAPH_MAX_BATCH', '4')
+    eng = Engine(spec, params, 'f16', max_batch=2, device=cuda)
+    out = torch.empty_like(ref)
+    for _ in range(4):                        # eager, capture, replay, replay
+        out.zero_()
+        eng.forward(x, out=out)
+        assert torch.equal(out, ref)
