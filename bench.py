@@ -183,7 +183,13 @@ def main():
     reps = 5
     layer_ms = eng.forward_timed(images, reps=reps)
     infos = eng.layer_infos()
-    conv_ms = sum(ms for ms, li in zip(layer_ms, infos) if li.kind == _lib.LAYER_CONV)
+    conv_ms_raw = sum(ms for ms, li in zip(layer_ms, infos) if li.kind == _lib.LAYER_CONV)
+    # An event pair around EVERY launch also times the ~2-3 us dependent-launch boundary it creates, so
+    # the per-layer sum (2.03 ms) exceeds the un-instrumented forward (1.83 ms, = the rocprofv3 kernel
+    # total).  The conv share of the per-layer breakdown is therefore applied to the forward time
+    # measured by ONE event pair around the timed steps on the same stream: this reproduces the
+    # rocprofv3 kernel-trace average for the conv kernels (profiles/*_kernel_stats.csv) within ~1 %.
+    conv_ms = conv_ms_raw * (gpu_ms / args.steps) / float(layer_ms.sum())
     conv_flops = sum(li.flops_per_image for li in infos if li.kind == _lib.LAYER_CONV) * b
     n_conv = sum(1 for li in infos if li.kind == _lib.LAYER_CONV)
     achieved_tflops = conv_flops / (conv_ms * 1e-3) / 1e12
@@ -236,6 +242,7 @@ def main():
                          'frac': round(achieved_tflops / PEAK_F16_DENSE_TFLOPS, 4), 'traffic': traffic,
                          'traffic_note': traffic_note,
                          'ms_per_forward_in_kernel': round(conv_ms, 4),
+                         'ms_per_forward_in_kernel_event_pairs_raw': round(conv_ms_raw, 4),
                          'algorithmic_gflop_per_forward': round(conv_flops / 1e9, 3)},
         }
         if world == 1 and args.cpu_seconds > 0:
