@@ -237,7 +237,7 @@ def main():
                        'gflop_per_crop': round(eng.flops_per_image / 1e9, 3)},
             'gpu_ms_per_step_events': round(gpu_ms / args.steps, 4),
             'whole_path_tflops': round(eng.flops_per_image * value / world / 1e12, 2),
-            'roofline': {'bound': 'mfma', 'kernel': f'conv_igemm_f16 ({n_conv} launches per forward)',
+            'roofline': {'bound': 'mfma', 'kernel': f'conv kernels: conv_igemm_f16_dma + conv3x3_f16_slab ({n_conv} launches per forward)',
                          'achieved': round(achieved_tflops, 2), 'peak': PEAK_F16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved_tflops / PEAK_F16_DENSE_TFLOPS, 4), 'traffic': traffic,
                          'traffic_note': traffic_note,

@@ -128,20 +128,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page);
     const unsigned smem_base = lds_offset_of(smem);
 
-    // ---- pre-activation BN parameters into LDS (behind the ring) --------------------------
-    half_t* pro_lds = reinterpret_cast<half_t*>(smem + Cfg::MAIN_BYTES);
-    if (PROLOGUE) {
-        const int cpad = kc_steps * BK;
-        for (int c = tid * 8; c < cpad; c += Cfg::NT * 8) {
-            uint4 sv = make_uint4(0, 0, 0, 0), bv = make_uint4(0, 0, 0, 0);
-            if (c < a.c_in) {
-                sv = *reinterpret_cast<const uint4*>(pro_scale + c);
-                bv = *reinterpret_cast<const uint4*>(pro_shift + c);
-            }
-            *reinterpret_cast<uint4*>(pro_lds + c) = sv;
-            *reinterpret_cast<uint4*>(pro_lds + 2048 + c) = bv;
-        }
-    }
+    half_t* pro_lds = reinterpret_cast<half_t*>(smem + Cfg::MAIN_BYTES);   // scale | shift (behind the ring)
 
     // ---- per-lane DMA source coordinates ----------------------------------------------------
     const int lrow = lane / CPR;    // row within the RPI-row group one DMA instruction fills
@@ -345,7 +332,27 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
     };
 
     // ---- main loop: STAGES-1 steps in flight -------------------------------------------------
-    if (PROLOGUE) __syncthreads();   // pro_lds written (also drains the ordinary loads above)
+    if constexpr (STAGES > 1) {
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nk) issue_step(s);
+    }
+    // ---- pre-activation BN parameters into LDS (behind the ring).  Done AFTER the first ring stages
+    // are in flight so that the latency of these ordinary loads overlaps the first DMAs.
+    if (PROLOGUE) {
+        const int cpad = kc_steps * BK;
+        for (int c = tid * 8; c < cpad; c += Cfg::NT * 8) {
+            uint4 sv = make_uint4(0, 0, 0, 0), bv = make_uint4(0, 0, 0, 0);
+            if (c < a.c_in) {
+                sv = *reinterpret_cast<const uint4*>(pro_scale + c);
+                bv = *reinterpret_cast<const uint4*>(pro_shift + c);
+            }
+            *reinterpret_cast<uint4*>(pro_lds + c) = sv;
+            *reinterpret_cast<uint4*>(pro_lds + 2048 + c) = bv;
+        }
+    }
+
+    if (PROLOGUE) __syncthreads();   // pro_lds written
     if constexpr (STAGES == 1) {
         // single slot (short-K layers: small LDS footprint -> several blocks per CU overlap instead)
         int cc0 = 0;
@@ -363,9 +370,6 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
             if (cc0 >= a.c_in) cc0 = 0;
         }
     } else {
-#pragma unroll
-        for (int s = 0; s < STAGES - 1; ++s)
-            if (s < nk) issue_step(s);
         int cbuf = 0, ibuf = STAGES - 1, cc0 = 0;
         auto advance = [&]() {
             cbuf = cbuf + 1 == STAGES ? 0 : cbuf + 1;
