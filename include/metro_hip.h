@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define METRO_ABI_VERSION 1
+#define METRO_ABI_VERSION 2
 
 typedef enum MetroStatus {
     METRO_OK = 0,
@@ -97,6 +97,9 @@ typedef struct MetroLayerInfo {
     int64_t out_offset;    /* byte offset of the output tensor in the workspace                  */
     int64_t out_bytes_per_image;
     double  flops_per_image; /* 2*MACs (convs only), SURVEY.md section 8d accounting              */
+    int64_t out2_offset;   /* fused launches with a second output tensor (shortcut+conv1 pairs,  */
+    int32_t out2_channels; /*   conv3+next conv1): its workspace offset / channels; -1 / 0 = none */
+    int32_t reserved;
 } MetroLayerInfo;
 
 /* ---- plan life cycle: replaces tf.import_graph_def of the frozen graph

@@ -5,9 +5,10 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libmetro_hip.so')
+LIB_PATH = os.environ.get('METRO_HIP_LIB') or os.path.join(HERE, 'libmetro_hip.so')   # override: timing experiments
 
 METRO_MAX_JOINTS = 64
+ABI_VERSION = 2          # include/metro_hip.h METRO_ABI_VERSION
 METRO_PREC_F16, METRO_PREC_F32, METRO_PREC_F64 = 0, 1, 2
 METRO_F16, METRO_F32, METRO_F64 = 0, 1, 2
 PARAM_CONV_W, PARAM_BIAS, PARAM_PRO_SCALE, PARAM_PRO_SHIFT = 0, 1, 2, 3
@@ -38,7 +39,8 @@ class MetroLayerInfo(C.Structure):
                 ('has_prologue', C.c_int32), ('relu', C.c_int32), ('has_residual', C.c_int32),
                 ('res_stride', C.c_int32), ('res_offset', C.c_int32), ('out_dtype', C.c_int32),
                 ('out_offset', C.c_int64), ('out_bytes_per_image', C.c_int64),
-                ('flops_per_image', C.c_double)]
+                ('flops_per_image', C.c_double),
+                ('out2_offset', C.c_int64), ('out2_channels', C.c_int32), ('reserved', C.c_int32)]
 
 
 class MetroConvDesc(C.Structure):
@@ -104,8 +106,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)            # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.metro_abi_version() != 1:
-        raise MetroError(f'ABI version mismatch: library {lib.metro_abi_version()}, bindings 1')
+    if lib.metro_abi_version() != ABI_VERSION:
+        raise MetroError(f'ABI version mismatch: library {lib.metro_abi_version()}, bindings {ABI_VERSION}')
     _lib = lib
     return lib
 

@@ -70,6 +70,9 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // is invisible to its bookkeeping; completion is ordered by the counted waits below.
 // lds_addr must be wave-uniform (it goes through M0, saved/restored around the instruction).
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
+#ifdef METRO_DBG_SKIP_LOAD    // timing experiments only (tools/build_dbg_variants.sh): results are garbage
+    return;
+#endif
     // M0 is written in the same statement that consumes it and is not preserved: nothing else in
     // these kernels uses M0 (gfx9+ LDS instructions do not need it).
     asm volatile(
@@ -89,16 +92,25 @@ __device__ __forceinline__ void wait_vm_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <class Cfg, bool PROLOGUE, bool FASTK>
-__global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
-    ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w,
+struct Fuse2Args {
+    const half_t* w2; const float* bias2; const half_t* scale2; const half_t* shift2; half_t* out2; int c2;
+};
+
+template <class Cfg, bool PROLOGUE, bool FASTK, bool FUSE2>
+__device__ __forceinline__ void conv_dma_body(
+    const ConvArgs& a, const half_t* __restrict__ in, const half_t* __restrict__ w,
     const float* __restrict__ bias, const half_t* __restrict__ pro_scale,
     const half_t* __restrict__ pro_shift, const half_t* __restrict__ residual,
-    void* __restrict__ out, int out_f32, int tiles_m, void* __restrict__ out2) {
+    void* __restrict__ out, int out_f32, int tiles_m, void* __restrict__ out2, const Fuse2Args& f2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = Cfg::BK, STAGES = Cfg::STAGES, NW = Cfg::NW;
     constexpr int CPR = Cfg::CPR, RPI = Cfg::RPI;
     constexpr int SLICES = BK / 16;
+    // FUSE2 LDS regions behind the main area: W2 image [c_out/64 chunks][64 rows][64 k] + scale2|shift2
+    // (W2 fragments fetched from L2 per tile instead measured 16 us slower per launch)
+    constexpr int F2_W_OFF = Cfg::MAIN_BYTES + (PROLOGUE ? Cfg::PRO_BYTES : 0);
+    constexpr int F2_W_BYTES = 64 * Cfg::TM * 2;
+    constexpr int F2_P_OFF = F2_W_OFF + F2_W_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -283,7 +295,11 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
             for (int i = 0; i < Cfg::WM; ++i)
 #pragma unroll
                 for (int j = 0; j < Cfg::WN; ++j)
+#ifdef METRO_DBG_SKIP_MFMA
+                    acc[i][j][0] += (float)af[i][0] * (float)bf[j][0];
+#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+#endif
 #ifdef METRO_SETPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -336,9 +352,30 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
             if (s < nk) issue_step(s);
+    } else {
+        issue_step(0);
     }
     // ---- pre-activation BN parameters into LDS (behind the ring).  Done AFTER the first ring stages
-    // are in flight so that the latency of these ordinary loads overlaps the first DMAs.
+    // are in flight so that the latency of these ordinary loads overlaps the first DMAs (a block that
+    // waits for them first pays a second, serial memory round trip: +30 us on block1's shortcut).
+    if constexpr (FUSE2) {
+        // W2 [64][TM] as TM/64 swizzled stage images of 64 rows x 64 k: issued before the residual
+        // prefetch, so the counted wait of the K step covers it; next unit's pre-activation scale/shift
+        // by ordinary loads (visible after the ring barrier)
+        static_assert(BK == 64 && (F2_W_BYTES / 1024) % NW == 0, "FUSE2 layout");
+#pragma unroll
+        for (int i = 0; i < F2_W_BYTES / 1024 / NW; ++i) {
+            const int vrow = (i * NW + wave) * 8 + (lane >> 3);          // row of the [TM/64 * 64][64] image
+            const int kc = vrow >> 6, r = vrow & 63;
+            const half_t* src = f2.w2 + (size_t)r * Cfg::TM + kc * 64 + (((lane & 7) ^ swzk<64>(r)) * 8);
+            dma16(src, __builtin_amdgcn_readfirstlane(smem_base + F2_W_OFF + (i * NW + wave) * 1024));
+        }
+        half_t* p2 = reinterpret_cast<half_t*>(smem + F2_P_OFF);
+        for (int c = tid * 8; c < Cfg::TM; c += Cfg::NT * 8) {
+            *reinterpret_cast<uint4*>(p2 + c) = *reinterpret_cast<const uint4*>(f2.scale2 + c);
+            *reinterpret_cast<uint4*>(p2 + Cfg::TM + c) = *reinterpret_cast<const uint4*>(f2.shift2 + c);
+        }
+    }
     if (PROLOGUE) {
         const int cpad = kc_steps * BK;
         for (int c = tid * 8; c < cpad; c += Cfg::NT * 8) {
@@ -357,8 +394,10 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
         // single slot (short-K layers: small LDS footprint -> several blocks per CU overlap instead)
         int cc0 = 0;
         for (int k = 0; k < nk; ++k) {
-            if (k > 0) wait_vm_and_barrier<0>();      // WAR: everyone is done reading the slot
-            issue_step(0);
+            if (k > 0) {
+                wait_vm_and_barrier<0>();             // WAR: everyone is done reading the slot
+                issue_step(0);
+            }
             if (has_res && k == nk - 1) {
                 prefetch_residual();
                 wait_vm_and_barrier<EPI_ITERS>();     // the step has landed; the residual may still fly
@@ -471,6 +510,8 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
             }
         }
     }
+    constexpr int T2M = 2, T2N = Cfg::TN / 32;              // 64 conv1 outputs x TN pixels in 32x32 MFMA tiles
+    constexpr int F2_KSTEPS = FUSE2 ? Cfg::TM / 16 : 1;
     __syncthreads();
     // 2) row-wise: 16 bytes per lane, (+ prefetched residual), full-line stores
     half_t* outh = reinterpret_cast<half_t*>(o_ptr);
@@ -490,7 +531,11 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = x[e] + r[e];    // fp16 Add, like the reference graph
             }
+#ifdef METRO_DBG_SKIP_STORE
+            if (a.m_total < 0)
+#endif
             *reinterpret_cast<uint4*>(outh + (size_t)m * o_c + co) = v;
+            if constexpr (FUSE2) *reinterpret_cast<uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16) = v;
         } else {
             // ragged channel tail (c_out % 8 != 0 never carries a residual: see conv_f16_dma_supported)
             const half8_t x = *reinterpret_cast<const half8_t*>(&v);
@@ -499,6 +544,62 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
                 if (co + e < o_c) outh[(size_t)m * o_c + co + e] = x[e];
         }
     }
+    if constexpr (FUSE2) {
+        // ---- second GEMM: t1 = relu(W2 * relu(x_out*scale2 + shift2) + bias2) from the LDS-resident tile ----
+        __syncthreads();                      // final x_out rows are back in LDS
+        if (wave < T2M * T2N) {
+            const int i2 = wave / T2N, j2 = wave % T2N;
+            floatx16 acc2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+            const half_t* p2 = reinterpret_cast<const half_t*>(smem + F2_P_OFF);
+            const int prow2 = j2 * 32 + frag_row;
+            const int arow = i2 * 32 + frag_row;
+            const char* w2l = smem + F2_W_OFF + arow * 128;
+#pragma unroll
+            for (int ks = 0; ks < F2_KSTEPS; ++ks) {
+                const int k0 = ks * 16 + frag_half * 8;
+                const half8_t af = *reinterpret_cast<const half8_t*>(
+                    w2l + (ks >> 2) * 8192 + ((((ks & 3) * 2 + frag_half) ^ swzk<64>(arow)) << 4));
+                half8_t bf = *reinterpret_cast<const half8_t*>(smem + prow2 * Cfg::OUT_ROW_BYTES + k0 * 2);
+                const half8_t sc = *reinterpret_cast<const half8_t*>(p2 + k0);
+                const half8_t sh = *reinterpret_cast<const half8_t*>(p2 + Cfg::TM + k0);
+                const half8_t z = {};
+                bf = __builtin_elementwise_max(bf * sc + sh, z);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc2, 0, 0, 0);
+            }
+            const int m = m0 + prow2;
+            if (m < a.m_total) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = i2 * 32 + 8 * q + 4 * frag_half;
+                    const floatx4 bv = *reinterpret_cast<const floatx4*>(f2.bias2 + co);
+                    half4_t hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[e] = (half_t)fmaxf(acc2[4 * q + e] + bv[e], 0.f);
+                    *reinterpret_cast<half4_t*>(f2.out2 + (size_t)m * f2.c2 + co) = hv;
+                }
+            }
+        }
+    }
+}
+
+template <class Cfg, bool PROLOGUE, bool FASTK>
+__global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_dma_kernel(
+    ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w,
+    const float* __restrict__ bias, const half_t* __restrict__ pro_scale,
+    const half_t* __restrict__ pro_shift, const half_t* __restrict__ residual,
+    void* __restrict__ out, int out_f32, int tiles_m, void* __restrict__ out2) {
+    conv_dma_body<Cfg, PROLOGUE, FASTK, false>(a, in, w, bias, pro_scale, pro_shift, residual, out, out_f32, tiles_m,
+                                               out2, Fuse2Args{});
+}
+
+// conv3 + next conv1 (block1)
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_fuse2_kernel(
+    ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w, const float* __restrict__ bias,
+    const half_t* __restrict__ residual, void* __restrict__ out, Fuse2Args f2) {
+    conv_dma_body<Cfg, false, true, true>(a, in, w, bias, nullptr, nullptr, residual, out, 0, 1, nullptr, f2);
 }
 
 static int env_int(const char* name, int dflt) {
@@ -556,6 +657,33 @@ using Dma64x128s3 = DmaCfg<1, 4, 2, 1, 3>;         //  64 x 128, 4 waves,  72 Ki
 using Dma64x128s1 = DmaCfg<1, 4, 2, 1, 1>;         //  64 x 128, 4 waves,  24 KiB
 using Dma64x128s3k32 = DmaCfg<1, 4, 2, 1, 3, 32>;  //  64 x 128, 4 waves, BK 32 (the stem's 32-wide taps)
 
+using DmaFuse256x64 = DmaCfg<4, 2, 2, 1, 1>;       // 256 cout x 64 px, 8 waves (wave 64 x 32), one K step: conv3 + next conv1
+
+bool conv_f16_fuse2_supported(const MetroConvDesc& d, int c2) {
+    static const int enabled = env_int("METRO_FUSE2", 1);
+    return enabled && d.c_out == DmaFuse256x64::TM && c2 == 64 && d.kh == 1 && d.kw == 1 && d.c_in == 64 &&
+           d.in_pix_stride == 64 && d.stride == 1 && d.pad_top == 0 && d.pad_left == 0 && !d.has_prologue &&
+           d.out_dtype == METRO_F16 && d.in_dtype == METRO_F16 && d.h_in == d.h_out && d.w_in == d.w_out;
+}
+
+static int launch_fuse2(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias, const half_t* res,
+                        void* out, const ConvFuse2& f, hipStream_t stream) {
+    using Cfg = DmaFuse256x64;
+    auto kern = conv_igemm_f16_fuse2_kernel<Cfg>;
+    constexpr int lds = Cfg::MAIN_BYTES + 64 * Cfg::TM * 2 + 2 * Cfg::TM * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(conv fuse2): %s", hipGetErrorString(e)); return METRO_ERR_HIP; }
+        attr_set = true;
+    }
+    const int tiles_n = (a.m_total + Cfg::TN - 1) / Cfg::TN;
+    hipLaunchKernelGGL(kern, dim3(tiles_n), dim3(Cfg::NT), lds, stream, a, in, w, bias, res, out,
+                       Fuse2Args{static_cast<const half_t*>(f.w2), f.bias2, static_cast<const half_t*>(f.scale2),
+                                 static_cast<const half_t*>(f.shift2), static_cast<half_t*>(f.out2), f.c2});
+    return launch_status("conv_igemm_f16_dma<fuse2>");
+}
+
 bool conv_f16_dma_supported(const MetroConvDesc& d) {
     // in_pix_stride % 4: the 4-channel bordered stem image gives 8-byte-aligned 16-byte sources
     return d.in_pix_stride % 4 == 0 && d.c_in % 8 == 0 && d.c_in <= 2048 && d.c_out % 4 == 0 &&
@@ -564,9 +692,16 @@ bool conv_f16_dma_supported(const MetroConvDesc& d) {
 
 int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_, const float* bias,
                         const void* ps_, const void* pb_, const void* res_, void* out, hipStream_t stream,
-                        const ConvSplit* split) {
+                        const ConvSplit* split, const ConvFuse2* fuse2) {
     ConvArgs a = make_conv_args(d);
     g_out2 = nullptr;
+    if (fuse2 != nullptr && fuse2->w2 != nullptr) {
+        if (!conv_f16_fuse2_supported(d, fuse2->c2)) { set_error("conv fuse2: unsupported layer shape (c_out %d c2 %d k %dx%d c_in %d pix_stride %d stride %d pad %d,%d pro %d dt %d/%d hw %dx%d -> %dx%d)",
+                                                                 d.c_out, fuse2->c2, d.kh, d.kw, d.c_in, d.in_pix_stride, d.stride, d.pad_top, d.pad_left, d.has_prologue,
+                                                                 d.in_dtype, d.out_dtype, d.h_in, d.w_in, d.h_out, d.w_out); return METRO_ERR_INVALID_ARG; }
+        return launch_fuse2(a, static_cast<const half_t*>(in_), static_cast<const half_t*>(w_), bias,
+                            d.has_residual ? static_cast<const half_t*>(res_) : nullptr, out, *fuse2, stream);
+    }
     if (split != nullptr && split->split > 0) {
         if (d.has_residual || d.out_dtype != METRO_F16 || split->split + split->c_out2 != d.c_out ||
             split->split % 256 != 0 || split->c_out2 % 8 != 0) {

@@ -51,6 +51,18 @@ struct ConvSplit {
     void* out2 = nullptr;
 };
 
+// conv3 of a unit + conv1 of the NEXT unit in one launch (block1: full 256-channel rows per pixel tile):
+// after the shortcut add, t1 = relu(W2 * relu(x_out * scale2 + shift2) + bias2) is computed from the
+// LDS-resident output tile (reference resnet_v2.py:119,127-128 of unit u+1 on the output of :138 of unit u).
+struct ConvFuse2 {
+    const void* w2 = nullptr;       // fp16 [c2][c_out], BN-folded
+    const float* bias2 = nullptr;   // [c2]
+    const void* scale2 = nullptr;   // fp16 [c_out]  (pre-activation BN of unit u+1)
+    const void* shift2 = nullptr;
+    void* out2 = nullptr;           // fp16 NHWC [.., c2]
+    int c2 = 0;
+};
+
 struct ConvArgs {
     int split, c_out2, relu2;   // see ConvSplit (0 = plain convolution)
     int n, h_in, w_in, c_in, in_pix_stride;
@@ -85,7 +97,8 @@ int launch_conv_f16(const MetroConvDesc& d, const void* in, const void* w, const
 bool conv_f16_dma_supported(const MetroConvDesc& d);
 int launch_conv_f16_dma(const MetroConvDesc& d, const void* in, const void* w, const float* bias,
                         const void* pro_scale, const void* pro_shift, const void* residual, void* out,
-                        hipStream_t stream, const ConvSplit* split = nullptr);
+                        hipStream_t stream, const ConvSplit* split = nullptr, const ConvFuse2* fuse2 = nullptr);
+bool conv_f16_fuse2_supported(const MetroConvDesc& d, int c2);
 // 3x3 stride-1 convs with tap reuse from an LDS-resident activation slab
 bool conv3x3_slab_supported(const MetroConvDesc& d);
 int launch_conv3x3_slab(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out,

@@ -69,6 +69,8 @@ struct Layer {
     int p_w, p_bias, p_scale, p_shift;
     // fused pair (projection shortcut + conv1 of the same unit, same pre-activated input):
     int split, c_out2, relu2, out2_slot;
+    // conv3 of unit u + conv1 of unit u+1 (ConvFuse2): parameter indices of the second GEMM, -1 = none
+    int f2_w, f2_bias, f2_scale, f2_shift, f2_c2;
 };
 
 }  // namespace
@@ -144,6 +146,7 @@ struct Builder {
                   int out_dtype, int in_dtype) {
         Layer L;
         memset(&L, 0, sizeof(L));
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
         L.kind = LK_CONV;
         const bool fast = p->fast;
         const int wdt = fast ? METRO_F16 : METRO_F64;
@@ -185,6 +188,7 @@ struct Builder {
                                  int c_sc, int cb, int adt) {
         Layer L;
         memset(&L, 0, sizeof(L));
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
         L.kind = LK_CONV;
         MetroConvDesc& cd = L.cd;
         cd.h_in = cd.w_in = side; cd.c_in = c_in; cd.in_pix_stride = c_in;
@@ -213,6 +217,28 @@ struct Builder {
         fill_info(L, un + "/shortcut+conv1", 2.0 * side * side * (double)(c_sc + cb) * c_in);
         L.info.c_out = c_sc;      // the primary output tensor (S_SC) has c_sc channels
         p->layers.push_back(L);
+    }
+
+    // Appends conv1 of the NEXT unit (1x1, cb outputs, folded BN + ReLU, pre-activation prologue of that
+    // unit) to the conv3 layer just added: the kernel runs it as a second GEMM on the LDS-resident output
+    // tile (reference resnet_v2.py:119,127-128 of unit u+1).  Parameter names stay those of the next unit.
+    void fuse_next_conv1(const std::string& un_next, const std::string& sc_next, int side, int c_in, int cb) {
+        Layer& L = p->layers.back();
+        const std::string conv_var = root + "/" + sc_next + "/conv1";
+        const std::string bn_var = conv_var + "/BatchNorm";
+        const std::string pv = root + "/" + sc_next + "/preact";
+        const std::string ln = un_next + "/conv1";
+        L.f2_w = add_param(ln + "/W", METRO_PARAM_CONV_W, conv_var, bn_var, METRO_F16, cb, 1, 1, c_in, 1, c_in);
+        L.f2_bias = add_param(ln + "/bias", METRO_PARAM_BIAS, conv_var, bn_var, METRO_F32, cb, 1, 1, 1, 1, 1);
+        L.f2_scale = add_param(ln + "/pro_scale", METRO_PARAM_PRO_SCALE, "", pv, METRO_F16, c_in, 1, 1, 1, 1, 1);
+        L.f2_shift = add_param(ln + "/pro_shift", METRO_PARAM_PRO_SHIFT, "", pv, METRO_F16, c_in, 1, 1, 1, 1, 1);
+        L.f2_c2 = cb; L.out2_slot = S_T1;
+        need(S_T1, (int64_t)side * side * cb * 2);
+        const double flops = 2.0 * side * side * (double)cb * c_in;
+        const std::string name = std::string(L.info.name) + "+" + un_next.substr(un_next.find('/') + 1) + "/conv1";
+        snprintf(L.info.name, sizeof(L.info.name), "%s", name.c_str());
+        L.info.flops_per_image += flops;
+        p->flops_per_image += flops;
     }
 
     void fill_info(Layer& L, const std::string& lname, double flops) {
@@ -254,6 +280,7 @@ int build_plan(MetroPlan* p) {
     if (fast) {
         Layer L;
         memset(&L, 0, sizeof(L));
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
         L.kind = LK_PREP;
         L.cd.h_in = L.cd.w_in = side; L.cd.c_in = 3;
         L.cd.h_out = side + 6; L.cd.w_out = side + 8; L.cd.c_out = 4; L.cd.out_dtype = METRO_F16;
@@ -268,6 +295,7 @@ int build_plan(MetroPlan* p) {
         // the 8th pixel and the 4th channel).
         Layer S;
         memset(&S, 0, sizeof(S));
+        S.f2_w = S.f2_bias = S.f2_scale = S.f2_shift = -1;
         S.kind = LK_CONV;
         MetroConvDesc& cd = S.cd;
         cd.h_in = side + 6; cd.w_in = side + 8; cd.c_in = 32; cd.in_pix_stride = 4;
@@ -290,6 +318,7 @@ int build_plan(MetroPlan* p) {
     {
         Layer L;
         memset(&L, 0, sizeof(L));
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
         L.kind = LK_POOL;
         L.cd.h_in = L.cd.w_in = s2; L.cd.c_in = bw; L.cd.h_out = L.cd.w_out = s4; L.cd.c_out = bw;
         L.cd.kh = L.cd.kw = 3; L.cd.stride = 2; L.cd.dilation = 1; L.cd.pad_top = L.cd.pad_left = 1;
@@ -321,6 +350,7 @@ int build_plan(MetroPlan* p) {
     const double output_stride = sp.stride / 4.0;    // resnet_v2.py:215 (float division)
     int current_stride = 1, rate = 1;
     int cur_side = s4, cur_c = bw, cur = S_X0;
+    bool conv1_done = false;      // conv1 of this unit already ran inside the previous unit's conv3 launch
     for (int b = 0; b < 4; ++b) {
         for (int u = 1; u <= n_units[b]; ++u) {
             const int unit_stride = u == n_units[b] ? block_stride[b] : 1;   // resnet_v2.py:260-269
@@ -343,7 +373,9 @@ int build_plan(MetroPlan* p) {
             // (block2/block3 of ResNet-50/101: -9 / -7 us); block1 (cb = 64: a half-empty tile) and block4 lose
             const bool fuse_pair = fast && project && s == 1 && cout % 256 == 0 && cur_c % 64 == 0 &&
                                    cb % 128 == 0 && cout <= 1024;
-            if (fuse_pair) {
+            if (conv1_done) {
+                conv1_done = false;       // S_T1 already holds relu(bn(conv1(preact(x))))
+            } else if (fuse_pair) {
                 B.add_shortcut_conv1_pair(un, sc, cur, cur_side, cur_c, cout, cb, adt);
             } else {
                 if (project) {
@@ -368,6 +400,16 @@ int build_plan(MetroPlan* p) {
             else
                 B.add_conv(un + "/conv3", sc + "/conv3", "", "", S_T2, nxt, cur, side_out, cb, side_out,
                            cout, 1, 1, 1, 0, false, cur_side, s, shift, adt, adt);
+            // block1 (full 256-channel rows per pixel tile): conv1 of the next unit rides in this launch
+            if (fast && u < n_units[b] && s == 1) {
+                MetroConvDesc probe = p->layers.back().cd;
+                probe.n = 1;
+                if (conv_f16_fuse2_supported(probe, cb)) {
+                    const std::string un2 = "block" + std::to_string(b + 1) + "/unit_" + std::to_string(u + 1);
+                    B.fuse_next_conv1(un2, un2 + "/bottleneck_v2", side_out, cout, cb);
+                    conv1_done = true;
+                }
+            }
             cur = nxt; cur_side = side_out; cur_c = cout;
         }
     }
@@ -383,6 +425,7 @@ int build_plan(MetroPlan* p) {
     {
         Layer L;
         memset(&L, 0, sizeof(L));
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
         L.kind = LK_SOFTARGMAX;
         L.cd.h_in = L.cd.w_in = cur_side; L.cd.c_in = c_head; L.cd.h_out = 1; L.cd.w_out = sp.n_joints_out;
         L.cd.c_out = 3; L.cd.out_dtype = METRO_F32;
@@ -405,6 +448,9 @@ int build_plan(MetroPlan* p) {
         L.info.out_offset = L.out_slot >= 0 ? p->slot_offset[L.out_slot] : -1;
         const int64_t es = L.cd.out_dtype == METRO_F16 ? 2 : L.cd.out_dtype == METRO_F32 ? 4 : 8;
         L.info.out_bytes_per_image = (int64_t)L.cd.h_out * L.cd.w_out * (L.split > 0 ? L.split : L.cd.c_out) * es;
+        const bool two = L.kind == LK_CONV && (L.split > 0 || L.f2_w >= 0);
+        L.info.out2_offset = two ? p->slot_offset[L.out2_slot] : -1;
+        L.info.out2_channels = two ? (L.split > 0 ? L.c_out2 : L.f2_c2) : 0;
     }
     return METRO_OK;
 }
@@ -451,6 +497,14 @@ int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_
                     sp.split = L.split; sp.c_out2 = L.c_out2; sp.relu2 = L.relu2; sp.out2 = slot_ptr(L.out2_slot);
                     st = launch_conv_f16_dma(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
                                              prm(L.p_scale), prm(L.p_shift), nullptr, slot_ptr(L.out_slot), stream, &sp);
+                } else if (p->fast && L.f2_w >= 0) {
+                    ConvFuse2 f2;
+                    f2.w2 = prm(L.f2_w); f2.bias2 = static_cast<const float*>(prm(L.f2_bias));
+                    f2.scale2 = prm(L.f2_scale); f2.shift2 = prm(L.f2_shift);
+                    f2.out2 = slot_ptr(L.out2_slot); f2.c2 = L.f2_c2;
+                    st = launch_conv_f16_dma(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
+                                             nullptr, nullptr, slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream,
+                                             nullptr, &f2);
                 } else if (p->fast)
                     st = launch_conv_f16(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
                                          prm(L.p_scale), prm(L.p_shift), slot_ptr(L.res_slot),

@@ -173,8 +173,9 @@ class Engine:
                                      C.c_void_p(stream)), 'metro_forward')
         return out
 
-    def forward_upto(self, images: torch.Tensor, layer: int) -> torch.Tensor:
-        """Runs layers [0..layer] and returns that layer's output tensor [n,h,w,c] (a copy)."""
+    def forward_upto(self, images: torch.Tensor, layer: int, second: bool = False) -> torch.Tensor:
+        """Runs layers [0..layer] and returns that layer's output tensor [n,h,w,c] (a copy); `second` selects
+        the second output of a fused launch (MetroLayerInfo.out2_offset)."""
         images = self._check_images(images)
         n = images.shape[0]
         li = self.layer_infos()[layer]
@@ -187,6 +188,12 @@ class Engine:
             return poses
         dt = {_lib.METRO_F16: torch.float16, _lib.METRO_F32: torch.float32,
               _lib.METRO_F64: torch.float64}[li.out_dtype]
+        if second:
+            if li.out2_offset < 0:
+                raise ValueError(f'{li.name.decode()}: layer has no second output')
+            nb2 = li.h_out * li.w_out * li.out2_channels * 2 * n
+            return self._ws[li.out2_offset:li.out2_offset + nb2].view(torch.float16).view(
+                n, li.h_out, li.w_out, li.out2_channels).clone()
         nbytes = li.out_bytes_per_image * n
         raw = self._ws[li.out_offset:li.out_offset + nbytes]
         return raw.view(dt).view(n, li.h_out, li.w_out, li.c_out).clone()

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/metro_hip.h but not exported'
     assert sorted(_lib.SIGNATURES) == declared, 'bindings and header disagree'
-    assert lib.metro_abi_version() == 1
+    assert lib.metro_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_ctypes_struct_layout_matches_compiler(tmp_path):
@@ -71,8 +71,22 @@ def test_planner_agrees_with_oracle_schedule(arch, stride, centered, prec):
     units = schedule(OracleSpec(arch=arch, stride=stride, centered_stride=centered))
     layers = {li.name.decode(): li for li in Engine(spec, None, prec, max_batch=1).layer_infos()}
     assert layers['conv1'].h_out == 128 and layers['pool1'].h_out == 64
+    # fp16 plans of full-width block1 run conv1 of unit u+1 inside the conv3 launch of unit u
+    fused_into = {}
+    for name, li in list(layers.items()):
+        if '/conv3+' in name:
+            unit, nxt = name.split('/conv3+')
+            layers[f'{unit}/conv3'] = li
+            fused_into[f'{unit.split("/")[0]}/{nxt[:-len("/conv1")]}'] = li
     for u in units:
         c2, c3 = (layers[f'{u.name}/conv{i}'] for i in (2, 3))
+        if u.name in fused_into:
+            host = fused_into[u.name]
+            assert prec == 'f16' and f'{u.name}/conv1' not in layers and u.c_in == u.c_out == host.c_out == 256
+            assert (host.out2_channels, host.h_out, host.kh, host.stride) == (u.c_bott, u.side_in, 1, 1)
+            assert host.out2_offset >= 0 and host.out2_offset != host.out_offset
+            assert (c2.kh, c2.stride, c2.dilation, c2.h_in, c2.h_out, c2.c_out) == (3, u.stride, u.rate, u.side_in, u.side_out, u.c_bott)
+            continue
         if f'{u.name}/shortcut+conv1' in layers:
             # fp16 plans fuse the projection shortcut and conv1 of a unit (same pre-activated input)
             pair = layers[f'{u.name}/shortcut+conv1']

@@ -55,8 +55,8 @@ def test_toy_layerwise(cuda, spec):
         for i, li in enumerate(eng.layer_infos()):
             name = li.name.decode()
             key = {'logits': 'logits', 'conv1': 'conv1', 'pool1': 'pool1'}.get(name)
-            if key is None and name.endswith('/conv3'):
-                key = name[:-len('/conv3')]                  # unit output = shortcut + conv3
+            if key is None and (name.endswith('/conv3') or '/conv3+' in name):
+                key = name.split('/conv3')[0]                # unit output = shortcut + conv3
             elif key is None and name.endswith(('/conv1', '/conv2')):
                 key = name
             if key is None or key not in col:
@@ -65,6 +65,49 @@ def test_toy_layerwise(cuda, spec):
             ref = col[key].permute(0, 2, 3, 1).numpy()
             err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
             assert err <= rel, (prec, name, err)
+
+
+def test_fused_launch_second_outputs(cuda):
+    """Launches with two output tensors (projection shortcut + conv1 pairs; block1 conv3 + the NEXT unit's
+    conv1 computed from the LDS-resident tile): both tensors against the oracle's intermediates, and the
+    second GEMM against a torch restatement on the kernel's own fp16 unit output (tight)."""
+    spec = ModelSpec(50, 32, 'h36m')                         # full width: block1 has 256-channel rows
+    params, images = _setup(spec, 3)
+    col = {}
+    OF.forward(H.oracle_spec(spec), params, images, torch.float64, col)
+    x = torch.from_numpy(images).to(cuda)
+    eng = Engine(spec, params, 'f16', max_batch=3, device=cuda)
+    seen = set()
+    for i, li in enumerate(eng.layer_infos()):
+        name = li.name.decode()
+        if li.out2_offset < 0:
+            continue
+        got2 = eng.forward_upto(x, i, second=True).cpu().double().numpy()
+        if '/conv3+' in name:
+            unit, nxt = name.split('/conv3+')
+            key2 = f'{unit.split("/")[0]}/{nxt}'
+            seen.add('conv3+conv1')
+            # tight: the second GEMM on the fp16 unit output the same launch stored
+            xo = eng.forward_upto(x, i).cpu().double()
+            sc = f'MainPart/resnet_v2_50/{key2[:-len("/conv1")]}/bottleneck_v2'
+            bn = lambda s, e=1e-5: (params[s + '/gamma'] / np.sqrt(params[s + '/moving_variance'] + e),
+                                    params[s + '/beta'], params[s + '/moving_mean'])
+            g, b, mu = bn(sc + '/preact')
+            pre = torch.relu(xo.half().double() * torch.from_numpy((g).astype(np.float16)).double()
+                             + torch.from_numpy((b - mu * g).astype(np.float16)).double())
+            pre = pre.half().double()          # the kernel applies the prologue in fp16
+            g1, b1, mu1 = bn(sc + '/conv1/BatchNorm')
+            w = (params[sc + '/conv1/weights'][0, 0] * g1[None, :]).astype(np.float16).astype(np.float64)   # [cin, cb]
+            want = torch.relu(pre @ torch.from_numpy(w) + torch.from_numpy((b1 - mu1 * g1).astype(np.float32)).double())
+            err = (torch.from_numpy(got2) - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+            assert err <= 4e-3, (name, err)
+        else:
+            key2 = name.replace('shortcut+conv1', 'conv1')
+            seen.add('shortcut+conv1')
+        ref2 = col[key2].permute(0, 2, 3, 1).numpy()
+        err = np.abs(got2 - ref2).max() / max(np.abs(ref2).max(), 1e-30)
+        assert err <= 3e-2, (name, 'second output', err)
+    assert seen == {'conv3+conv1', 'shortcut+conv1'}
 
 
 def test_full_rn50_s16_all_modes(cuda):
