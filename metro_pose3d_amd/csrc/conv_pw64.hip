@@ -1,0 +1,365 @@
+// Persistent, software-pipelined 1x1 convolution for block1's 64-channel tensors (c_in = 64, c_out = 256).
+//
+// These layers (projection shortcut, conv1, conv3 of resnet_v2 block1 at 64x64: reference resnet_v2.py:120-138)
+// move 170-340 MB per launch against 2-17 GFLOP: they are pure memory streams.  The tiled kernel
+// (conv_igemm_f16_dma.hip) runs them as 4096 short-lived blocks whose load -> MFMA -> transpose -> store
+// chains do not overlap (measured: 77-94 us where a plain copy of the same bytes takes 30-60 us, and removing
+// either the stores or the MFMAs barely helps).  Here ONE block per CU stays resident and walks over pixel
+// tiles (64 pixels x all 256 output channels = full 512-byte NHWC rows):
+//   * the weights live in registers as MFMA A-fragments for the whole launch (32 VGPRs per lane);
+//   * the next tile's input rows (8 KB) and shortcut rows (32 KB) are LDS-DMA'd while the current tile is
+//     computed: each wave reads back only the shortcut bytes it requested itself, so they need no barrier;
+//   * ordering is by counted s_waitcnt vmcnt(N): the only younger VMEM operations than the next tile's
+//     loads are the current tile's stores, whose number per wave is fixed;
+//   * the barriers are raw s_barrier (a __syncthreads() would drain the stores: vmcnt(0));
+//   * optional second output (64 channels):
+//       MODE2 = 1  extra weight rows on the SAME input (conv1 of the unit next to its projection shortcut,
+//                  reference resnet_v2.py:122-128): 4 more MFMAs on the B fragments already in registers;
+//       MODE2 = 2  conv1 of the NEXT unit on this launch's output (after the shortcut add), pre-activation
+//                  applied in the row-wise pass, second GEMM from the LDS-resident tile (resnet_v2.py:119,127).
+// Arithmetic is that of the tiled kernel: fp32 accumulate, fp16(conv + bias), then the fp16 shortcut add.
+#include <cstdlib>
+
+#include "metro_common.h"
+
+namespace metro {
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page_pw[4];   // zero-initialised
+
+struct Pw64Args {
+    const half_t* in;          // [m_total][64]
+    const half_t* w;           // [256][64]
+    const float* bias;         // [256]
+    const half_t* pro_scale;   // [64]  (PRO)
+    const half_t* pro_shift;
+    const half_t* residual;    // [m_total][256]  (RES)
+    half_t* out;               // [m_total][256]
+    const half_t* w2;          // MODE2 = 1: [64][64];  MODE2 = 2: [64][256]
+    const float* bias2;        // [64]
+    const half_t* scale2;      // [256]  (MODE2 = 2)
+    const half_t* shift2;
+    half_t* out2;              // [m_total][64]
+    int m_total, n_tiles;
+};
+
+namespace pw {
+constexpr int TN = 64;                         // pixels per tile
+constexpr int NW = 8, NT = 512;
+constexpr int X_BYTES = TN * 128;              // one input tile: 64 rows x 64 fp16
+constexpr int OUT_ROW = 256 * 2 + 16;          // padded rows of the [pixel][cout] tile
+constexpr int OUT_BYTES = TN * OUT_ROW;
+constexpr int RES_BYTES = TN * 512;
+constexpr int X_OFF = 0;                       // 2 buffers
+constexpr int OUT_OFF = X_OFF + 2 * X_BYTES;
+constexpr int PAR_OFF = OUT_OFF + OUT_BYTES;   // bias[256] f32 | bias2[64] f32 | pro scale[64] | pro shift[64] fp16
+constexpr int PAR_BYTES = 1024 + 256 + 128 + 128;
+constexpr int RES_OFF = PAR_OFF + PAR_BYTES;   // 2 buffers (RES)
+template <bool RES, int MODE2>
+constexpr int lds_bytes() { return RES_OFF + (RES ? 2 * RES_BYTES : 0) + (MODE2 == 2 ? 64 * 256 * 2 : 0); }
+}  // namespace pw
+
+__device__ __forceinline__ int pw_swz(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ void pw_dma16(const void* gsrc, unsigned lds_addr) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(gsrc), "s"(lds_addr));
+}
+template <int N>
+__device__ __forceinline__ void pw_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pw_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool PRO, bool RES, int MODE2>
+__global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
+    using namespace pw;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    const unsigned smem_base = (unsigned)(size_t)(lds_void_t*)smem;
+    constexpr int W2_OFF = RES_OFF + (RES ? 2 * RES_BYTES : 0);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;            // wave tile: couts wm*64..+64, pixels wn*32..+32
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+    const int G = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= a.n_tiles) return;
+    const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page_pw);
+
+    // ---- launch-resident operands ------------------------------------------------------------
+    half8_t wf[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(wm * 64 + i * 32 + frag_row) * 64 + kk * 16 + frag_half * 8);
+    half8_t w2f[4];
+    if constexpr (MODE2 == 1) {
+        if (wave < 4) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                w2f[kk] = *reinterpret_cast<const half8_t*>(a.w2 + (size_t)(wm * 32 + frag_row) * 64 + kk * 16 + frag_half * 8);
+        }
+    }
+    float* bias_l = reinterpret_cast<float*>(smem + PAR_OFF);
+    float* bias2_l = bias_l + 256;
+    half_t* pro_l = reinterpret_cast<half_t*>(smem + PAR_OFF + 1280);
+    if (tid < 256) bias_l[tid] = a.bias[tid];
+    if (MODE2 != 0 && tid < 64) bias2_l[tid] = a.bias2[tid];
+    if (PRO && tid < 64) { pro_l[tid] = a.pro_scale[tid]; pro_l[64 + tid] = a.pro_shift[tid]; }
+    // row-wise pass: this thread always owns 16-byte chunk `ch` of a row
+    const int ch = tid & 31;
+    half8_t sc2 = {}, sh2 = {};
+    if constexpr (MODE2 == 2) {
+        sc2 = *reinterpret_cast<const half8_t*>(a.scale2 + ch * 8);
+        sh2 = *reinterpret_cast<const half8_t*>(a.shift2 + ch * 8);
+        // W2 [64][256] as 4 swizzled images of 64 rows x 64 k (one per 64-channel slice of K)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vrow = (i * NW + wave) * 8 + (lane >> 3);
+            const int kc = vrow >> 6, r = vrow & 63;
+            const half_t* src = a.w2 + (size_t)r * 256 + kc * 64 + (((lane & 7) ^ pw_swz(r)) * 8);
+            pw_dma16(src, __builtin_amdgcn_readfirstlane(smem_base + W2_OFF + (i * NW + wave) * 1024));
+        }
+    }
+
+    // ---- per-lane DMA coordinates ------------------------------------------------------------
+    const int xrow = wave * 8 + (lane >> 3);                       // input row this lane fetches 16 bytes of
+    const int xoff = xrow * 64 + (((lane & 7) ^ pw_swz(xrow)) * 8);
+    auto issue_tile = [&](int tile, int buf) {
+        const int m0 = tile * TN;
+        const half_t* xs = (m0 + xrow < a.m_total) ? a.in + (size_t)m0 * 64 + xoff : zero;
+        pw_dma16(xs, __builtin_amdgcn_readfirstlane(smem_base + X_OFF + buf * X_BYTES + wave * 1024));
+        if constexpr (RES) {
+            // the tile's shortcut rows are one contiguous 32 KB block; chunk c = it*512 + tid lands at c*16
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int c = it * NT + tid;
+                const half_t* rs = (m0 + (c >> 5) < a.m_total) ? a.residual + (size_t)m0 * 256 + c * 8 : zero;
+                pw_dma16(rs, __builtin_amdgcn_readfirstlane(smem_base + RES_OFF + buf * RES_BYTES + it * 8192 + wave * 1024));
+            }
+        }
+    };
+
+    issue_tile(t, 0);
+    // stores of one tile per wave (all younger than the next tile's loads): 4 row-wise (+4 second-output)
+    const bool two = MODE2 != 0 && wave < 4;
+    bool prev_full = false;
+    for (int it = 0;; ++it, t += G) {
+        const int buf = it & 1;
+        const int m0 = t * TN;
+        // ---- the tile's loads have landed (for this wave), then for every wave -----------------
+        if (it == 0 || !prev_full) pw_wait_vm<0>();
+        else if (two) pw_wait_vm<8>();
+        else pw_wait_vm<4>();
+        pw_barrier();
+        if (t + G < a.n_tiles) issue_tile(t + G, buf ^ 1);
+        prev_full = m0 + TN <= a.m_total;
+
+        // ---- GEMM 1: [256 x 64] x [64 x 64 pixels] ---------------------------------------------
+        floatx16 acc[2], acc2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; acc2[e] = 0.f; }
+        const char* xl = smem + X_OFF + buf * X_BYTES;
+        const int brow = wn * 32 + frag_row;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int chunk = kk * 2 + frag_half;
+            half8_t bf = *reinterpret_cast<const half8_t*>(xl + brow * 128 + ((chunk ^ pw_swz(brow)) << 4));
+            if constexpr (PRO) {
+                const half8_t s = *reinterpret_cast<const half8_t*>(pro_l + chunk * 8);
+                const half8_t b = *reinterpret_cast<const half8_t*>(pro_l + 64 + chunk * 8);
+                const half8_t z = {};
+                bf = __builtin_elementwise_max(bf * s + b, z);
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][kk], bf, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][kk], bf, acc[1], 0, 0, 0);
+            if constexpr (MODE2 == 1) {
+                if (wave < 4) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[kk], bf, acc2, 0, 0, 0);
+            }
+        }
+        if constexpr (MODE2 == 1) {
+            // conv1 rows: relu(acc + bias2) -> out2[m][64]   (waves 0..3: couts wm*32.., pixels wn*32..)
+            if (wave < 4) {
+                const int m = m0 + wn * 32 + frag_row;
+                if (m < a.m_total) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = wm * 32 + 8 * q + 4 * frag_half;
+                        const floatx4 bv = *reinterpret_cast<const floatx4*>(bias2_l + co);
+                        half4_t hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = (half_t)fmaxf(acc2[4 * q + e] + bv[e], 0.f);
+                        *reinterpret_cast<half4_t*>(a.out2 + (size_t)m * 64 + co) = hv;
+                    }
+                }
+            }
+        }
+        // ---- accumulators (+bias) -> LDS tile [pixel][cout] fp16 -------------------------------
+        char* ol = smem + OUT_OFF;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = (wm * 2 + i) * 32 + 8 * q + 4 * frag_half;
+                const floatx4 bv = *reinterpret_cast<const floatx4*>(bias_l + col);
+                half4_t hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (half_t)(acc[i][4 * q + e] + bv[e]);
+                *reinterpret_cast<half4_t*>(ol + brow * OUT_ROW + col * 2) = hv;
+            }
+        }
+        pw_barrier();
+        // ---- row-wise: 16 bytes per lane, + shortcut, full-row stores ---------------------------
+        const char* rl = smem + RES_OFF + buf * RES_BYTES;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = tid + r * NT;
+            const int prow = idx >> 5;
+            const int m = m0 + prow;
+            uint4 v = *reinterpret_cast<const uint4*>(ol + prow * OUT_ROW + ch * 16);
+            if constexpr (RES) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(rl + idx * 16);
+                half2_t* x = reinterpret_cast<half2_t*>(&v);
+                const half2_t* rr = reinterpret_cast<const half2_t*>(&rv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = x[e] + rr[e];       // fp16 Add, like the reference graph
+            }
+            if (m < a.m_total) *reinterpret_cast<uint4*>(a.out + (size_t)m * 256 + ch * 8) = v;
+            if constexpr (MODE2 == 2) {
+                // next unit's pre-activation (fp16 BN + ReLU) goes back into the tile for the second GEMM
+                const half8_t z = {};
+                half8_t p = *reinterpret_cast<const half8_t*>(&v);
+                p = __builtin_elementwise_max(p * sc2 + sh2, z);
+                *reinterpret_cast<half8_t*>(ol + prow * OUT_ROW + ch * 16) = p;
+            }
+        }
+        if constexpr (MODE2 == 2) {
+            pw_barrier();
+            // ---- GEMM 2: [64 x 256] x [256 x 64 pixels] from the tile (waves 0..3, one 32x32 tile each)
+            if (wave < 4) {
+                const int arow = wm * 32 + frag_row;
+                const char* w2l = smem + W2_OFF + arow * 128;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int k0 = ks * 16 + frag_half * 8;
+                    const half8_t af = *reinterpret_cast<const half8_t*>(
+                        w2l + (ks >> 2) * 8192 + ((((ks & 3) * 2 + frag_half) ^ pw_swz(arow)) << 4));
+                    const half8_t bf = *reinterpret_cast<const half8_t*>(ol + brow * OUT_ROW + k0 * 2);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc2, 0, 0, 0);
+                }
+                const int m = m0 + brow;
+                if (m < a.m_total) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = wm * 32 + 8 * q + 4 * frag_half;
+                        const floatx4 bv = *reinterpret_cast<const floatx4*>(bias2_l + co);
+                        half4_t hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = (half_t)fmaxf(acc2[4 * q + e] + bv[e], 0.f);
+                        *reinterpret_cast<half4_t*>(a.out2 + (size_t)m * 64 + co) = hv;
+                    }
+                }
+            }
+        }
+        if (t + G >= a.n_tiles) break;
+    }
+}
+
+static int pw_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+static bool pw_enabled() {
+    static const int v = pw_env_int("METRO_PW64", 1);
+    return v != 0;
+}
+
+// mode: 0 plain, 1 shortcut + conv1 pair (desc.c_out = 320 = 256 + 64 concatenated rows), 2 conv3 + next conv1
+bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
+    if (!pw_enabled()) return false;
+    const int c_out = mode == 1 ? 320 : 256;
+    if (!(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_top == 0 && d.pad_left == 0 && d.c_in == 64 &&
+          d.in_pix_stride == 64 && d.c_out == c_out && d.h_in == d.h_out && d.w_in == d.w_out && d.relu == 0 &&
+          d.out_dtype == METRO_F16 && d.in_dtype == METRO_F16))
+        return false;
+    if (d.has_residual && !(d.res_stride == 1 && d.res_offset == 0 && d.res_h == d.h_out && d.res_w == d.w_out)) return false;
+    // built combinations: prologue without shortcut (projection shortcut, pair) / shortcut without prologue (conv3)
+    if (mode == 1) return d.has_prologue && !d.has_residual;
+    if (mode == 2) return !d.has_prologue && d.has_residual;
+    return (d.has_prologue != 0) != (d.has_residual != 0);
+}
+
+template <bool PRO, bool RES, int MODE2>
+static int launch_pw(const Pw64Args& a, hipStream_t stream) {
+    auto kern = conv_pw64_kernel<PRO, RES, MODE2>;
+    constexpr int lds = pw::lds_bytes<RES, MODE2>();
+    static int grid_cap = 0;
+    if (grid_cap == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(conv_pw64): %s", hipGetErrorString(e)); return METRO_ERR_HIP; }
+        int dev = 0, cus = 0, occ = 0;
+        METRO_HIP_CHECK(hipGetDevice(&dev));
+        METRO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        METRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, pw::NT, lds));
+        const int cap = pw_env_int("METRO_PW64_BPC", 0);          // blocks per CU (0 = what fits)
+        if (occ < 1) occ = 1;
+        if (cap > 0 && cap < occ) occ = cap;
+        grid_cap = cus * occ;
+    }
+    const int grid = a.n_tiles < grid_cap ? a.n_tiles : grid_cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(pw::NT), lds, stream, a);
+    return launch_status("conv_pw64");
+}
+
+int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* ps,
+                     const void* pb, const void* res, void* out, hipStream_t stream, const ConvSplit* split,
+                     const ConvFuse2* f2) {
+    const int mode = (f2 != nullptr && f2->w2 != nullptr) ? 2 : (split != nullptr && split->split > 0) ? 1 : 0;
+    if (!conv_pw64_supported(d, mode) || (mode == 1 && !(split->split == 256 && split->c_out2 == 64 && split->relu2 == 1)) ||
+        (mode == 2 && f2->c2 != 64)) {
+        set_error("conv_pw64: unsupported layer");
+        return METRO_ERR_INVALID_ARG;
+    }
+    Pw64Args a;
+    a.in = static_cast<const half_t*>(in);
+    a.w = static_cast<const half_t*>(w);
+    a.bias = bias;
+    a.pro_scale = static_cast<const half_t*>(ps);
+    a.pro_shift = static_cast<const half_t*>(pb);
+    a.residual = d.has_residual ? static_cast<const half_t*>(res) : nullptr;
+    a.out = static_cast<half_t*>(out);
+    a.w2 = nullptr; a.bias2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out2 = nullptr;
+    a.m_total = d.n * d.h_out * d.w_out;
+    a.n_tiles = (a.m_total + pw::TN - 1) / pw::TN;
+    if (mode == 1) {
+        a.w2 = a.w + 256 * 64; a.bias2 = bias + 256; a.out2 = static_cast<half_t*>(split->out2);
+        return launch_pw<true, false, 1>(a, stream);
+    }
+    if (mode == 2) {
+        a.w2 = static_cast<const half_t*>(f2->w2); a.bias2 = f2->bias2;
+        a.scale2 = static_cast<const half_t*>(f2->scale2); a.shift2 = static_cast<const half_t*>(f2->shift2);
+        a.out2 = static_cast<half_t*>(f2->out2);
+        return launch_pw<false, true, 2>(a, stream);
+    }
+    if (d.has_prologue) return launch_pw<true, false, 0>(a, stream);
+    return launch_pw<false, true, 0>(a, stream);
+}
+
+}  // namespace metro

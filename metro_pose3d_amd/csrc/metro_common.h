@@ -99,6 +99,12 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in, const void* w, c
                         const void* pro_scale, const void* pro_shift, const void* residual, void* out,
                         hipStream_t stream, const ConvSplit* split = nullptr, const ConvFuse2* fuse2 = nullptr);
 bool conv_f16_fuse2_supported(const MetroConvDesc& d, int c2);
+// persistent pipelined kernel for block1's 64-channel 1x1 convolutions (conv_pw64.hip); mode: 0 plain,
+// 1 projection shortcut + conv1 pair (c_out = 256 + 64 concatenated rows), 2 conv3 + the next unit's conv1
+bool conv_pw64_supported(const MetroConvDesc& d, int mode);
+int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* pro_scale,
+                     const void* pro_shift, const void* residual, void* out, hipStream_t stream,
+                     const ConvSplit* split, const ConvFuse2* fuse2);
 // 3x3 stride-1 convs with tap reuse from an LDS-resident activation slab
 bool conv3x3_slab_supported(const MetroConvDesc& d);
 int launch_conv3x3_slab(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out,

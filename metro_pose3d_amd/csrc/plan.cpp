@@ -371,8 +371,19 @@ int build_plan(MetroPlan* p) {
             const bool project = cur_c != cout;                              // resnet_v2.py:120-125
             // measured on MI355X (batch 64): pays when conv1 fills whole 128-cout tiles and the pair is not huge
             // (block2/block3 of ResNet-50/101: -9 / -7 us); block1 (cb = 64: a half-empty tile) and block4 lose
+            // block1 (cb = 64: a half-empty tile in the tiled kernel) pairs only in the persistent kernel
+            bool pw_pair = false;
+            if (fast && project && s == 1 && cur_c == 64 && cout == 256 && cb == 64) {
+                MetroConvDesc probe;
+                memset(&probe, 0, sizeof(probe));
+                probe.n = 1; probe.h_in = probe.w_in = probe.h_out = probe.w_out = cur_side;
+                probe.c_in = probe.in_pix_stride = cur_c; probe.c_out = cout + cb;
+                probe.kh = probe.kw = 1; probe.stride = 1; probe.dilation = 1; probe.has_prologue = 1;
+                probe.out_dtype = probe.in_dtype = METRO_F16; probe.res_stride = 1;
+                pw_pair = conv_pw64_supported(probe, 1);
+            }
             const bool fuse_pair = fast && project && s == 1 && cout % 256 == 0 && cur_c % 64 == 0 &&
-                                   cb % 128 == 0 && cout <= 1024;
+                                   ((cb % 128 == 0 && cout <= 1024) || pw_pair);
             if (conv1_done) {
                 conv1_done = false;       // S_T1 already holds relu(bn(conv1(preact(x))))
             } else if (fuse_pair) {

@@ -19,6 +19,10 @@ pytestmark = pytest.mark.gpu
 CONV_CASES = [
     ('1x1', 2, 16, 64, 256, 1, 1, 1, 0, 16),
     ('1x1_ragged_m', 3, 7, 64, 64, 1, 1, 1, 0, 7),
+    # persistent pipelined kernel (conv_pw64.hip; prologue / residual variants): ragged last tile, and more
+    # tiles than resident blocks so every block walks several tiles through its double buffers
+    ('1x1_pw64_ragged', 3, 7, 64, 256, 1, 1, 1, 0, 7),
+    ('1x1_pw64_many_tiles', 25, 64, 64, 256, 1, 1, 1, 0, 64),
     ('1x1_head136', 2, 16, 128, 136, 1, 1, 1, 0, 16),
     ('1x1_cin_tail', 2, 8, 24, 64, 1, 1, 1, 0, 8),
     ('3x3_s1', 2, 16, 64, 64, 3, 1, 1, 1, 16),
