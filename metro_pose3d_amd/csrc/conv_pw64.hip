@@ -47,22 +47,26 @@ struct Pw64Args {
     const half_t* shift2;
     half_t* out2;              // [m_total][64]
     int m_total, n_tiles;
+    int c_out;                 // 256 * (number of 256-channel halves); block b serves half b % halves
 };
 
 namespace pw {
 constexpr int TN = 64;                         // pixels per tile
 constexpr int NW = 8, NT = 512;
-constexpr int X_BYTES = TN * 128;              // one input tile: 64 rows x 64 fp16
 constexpr int OUT_ROW = 256 * 2 + 16;          // padded rows of the [pixel][cout] tile
 constexpr int OUT_BYTES = TN * OUT_ROW;
 constexpr int RES_BYTES = TN * 512;
-constexpr int X_OFF = 0;                       // 2 buffers
-constexpr int OUT_OFF = X_OFF + 2 * X_BYTES;
-constexpr int PAR_OFF = OUT_OFF + OUT_BYTES;   // bias[256] f32 | bias2[64] f32 | pro scale[64] | pro shift[64] fp16
-constexpr int PAR_BYTES = 1024 + 256 + 128 + 128;
-constexpr int RES_OFF = PAR_OFF + PAR_BYTES;   // 2 buffers (RES)
-template <bool RES, int MODE2>
-constexpr int lds_bytes() { return RES_OFF + (RES ? 2 * RES_BYTES : 0) + (MODE2 == 2 ? 64 * 256 * 2 : 0); }
+constexpr int PAR_BYTES = 1024 + 256 + 256 + 256;   // bias[256] f32 | bias2[64] f32 | pro scale[K<=128] | pro shift fp16
+template <int K>
+struct Lay {
+    static constexpr int X_BYTES = TN * K * 2;     // one input tile: K/64 swizzled slices of 64 rows x 64 fp16
+    static constexpr int X_OFF = 0;                // 2 buffers
+    static constexpr int OUT_OFF = X_OFF + 2 * X_BYTES;
+    static constexpr int PAR_OFF = OUT_OFF + OUT_BYTES;
+    static constexpr int RES_OFF = PAR_OFF + PAR_BYTES;   // 2 buffers (RES)
+};
+template <int K, bool RES, int MODE2>
+constexpr int lds_bytes() { return Lay<K>::RES_OFF + (RES ? 2 * RES_BYTES : 0) + (MODE2 == 2 ? 64 * 256 * 2 : 0); }
 }  // namespace pw
 
 __device__ __forceinline__ int pw_swz(int row) { return (row >> 1) & 7; }
@@ -83,9 +87,14 @@ __device__ __forceinline__ void pw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool PRO, bool RES, int MODE2>
+template <int K, bool PRO, bool RES, int MODE2>
 __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     using namespace pw;
+    static_assert(K == 64 || K == 128, "weights must fit the register file as MFMA fragments");
+    static_assert(MODE2 == 0 || K == 64, "second outputs are block1 shapes");
+    constexpr int KK = K / 16, KS = K / 64;
+    constexpr int X_BYTES = Lay<K>::X_BYTES, X_OFF = Lay<K>::X_OFF, OUT_OFF = Lay<K>::OUT_OFF, PAR_OFF = Lay<K>::PAR_OFF,
+                  RES_OFF = Lay<K>::RES_OFF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void_t;
     const unsigned smem_base = (unsigned)(size_t)(lds_void_t*)smem;
@@ -96,18 +105,26 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;            // wave tile: couts wm*64..+64, pixels wn*32..+32
     const int frag_row = lane & 31, frag_half = lane >> 5;
-    const int G = gridDim.x;
-    int t = blockIdx.x;
+    // 256-channel halves of wider outputs go to different blocks (the weights are register-resident)
+    const int halves = a.c_out >> 8;
+    const int half = blockIdx.x % halves;
+    const int G = gridDim.x / halves;
+    int t = blockIdx.x / halves;
     if (t >= a.n_tiles) return;
+    a.w += (size_t)half * 256 * K;
+    a.bias += half * 256;
+    a.out += half * 256;
+    if (RES) a.residual += half * 256;
+    const int ldo = a.c_out;
     const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page_pw);
 
     // ---- launch-resident operands ------------------------------------------------------------
-    half8_t wf[2][4];
+    half8_t wf[2][KK];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(wm * 64 + i * 32 + frag_row) * 64 + kk * 16 + frag_half * 8);
+        for (int kk = 0; kk < KK; ++kk)
+            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(wm * 64 + i * 32 + frag_row) * K + kk * 16 + frag_half * 8);
     half8_t w2f[4];
     if constexpr (MODE2 == 1) {
         if (wave < 4) {
@@ -121,7 +138,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     half_t* pro_l = reinterpret_cast<half_t*>(smem + PAR_OFF + 1280);
     if (tid < 256) bias_l[tid] = a.bias[tid];
     if (MODE2 != 0 && tid < 64) bias2_l[tid] = a.bias2[tid];
-    if (PRO && tid < 64) { pro_l[tid] = a.pro_scale[tid]; pro_l[64 + tid] = a.pro_shift[tid]; }
+    if (PRO && tid < K) { pro_l[tid] = a.pro_scale[tid]; pro_l[K + tid] = a.pro_shift[tid]; }
     // row-wise pass: this thread always owns 16-byte chunk `ch` of a row
     const int ch = tid & 31;
     half8_t sc2 = {}, sh2 = {};
@@ -139,18 +156,23 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     }
 
     // ---- per-lane DMA coordinates ------------------------------------------------------------
+    // input tile = K/64 slices [64 rows][64 k] (128-byte rows, chunk-swizzled); slice j of this wave's 8 rows
     const int xrow = wave * 8 + (lane >> 3);                       // input row this lane fetches 16 bytes of
-    const int xoff = xrow * 64 + (((lane & 7) ^ pw_swz(xrow)) * 8);
+    const int xoff = xrow * K + (((lane & 7) ^ pw_swz(xrow)) * 8);
     auto issue_tile = [&](int tile, int buf) {
         const int m0 = tile * TN;
-        const half_t* xs = (m0 + xrow < a.m_total) ? a.in + (size_t)m0 * 64 + xoff : zero;
-        pw_dma16(xs, __builtin_amdgcn_readfirstlane(smem_base + X_OFF + buf * X_BYTES + wave * 1024));
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const half_t* xs = (m0 + xrow < a.m_total) ? a.in + (size_t)m0 * K + xoff + j * 64 : zero;
+            pw_dma16(xs, __builtin_amdgcn_readfirstlane(smem_base + X_OFF + buf * X_BYTES + j * 8192 + wave * 1024));
+        }
         if constexpr (RES) {
-            // the tile's shortcut rows are one contiguous 32 KB block; chunk c = it*512 + tid lands at c*16
+            // shortcut rows: chunk c = it*512 + tid (row c/32, 16-byte column c%32) lands at c*16, i.e. every
+            // wave later reads back exactly the bytes it requested
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int c = it * NT + tid;
-                const half_t* rs = (m0 + (c >> 5) < a.m_total) ? a.residual + (size_t)m0 * 256 + c * 8 : zero;
+                const half_t* rs = (m0 + (c >> 5) < a.m_total) ? a.residual + (size_t)(m0 + (c >> 5)) * ldo + (c & 31) * 8 : zero;
                 pw_dma16(rs, __builtin_amdgcn_readfirstlane(smem_base + RES_OFF + buf * RES_BYTES + it * 8192 + wave * 1024));
             }
         }
@@ -178,12 +200,12 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         const char* xl = smem + X_OFF + buf * X_BYTES;
         const int brow = wn * 32 + frag_row;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int chunk = kk * 2 + frag_half;
-            half8_t bf = *reinterpret_cast<const half8_t*>(xl + brow * 128 + ((chunk ^ pw_swz(brow)) << 4));
+        for (int kk = 0; kk < KK; ++kk) {
+            const int chunk = (kk & 3) * 2 + frag_half;
+            half8_t bf = *reinterpret_cast<const half8_t*>(xl + (kk >> 2) * 8192 + brow * 128 + ((chunk ^ pw_swz(brow)) << 4));
             if constexpr (PRO) {
-                const half8_t s = *reinterpret_cast<const half8_t*>(pro_l + chunk * 8);
-                const half8_t b = *reinterpret_cast<const half8_t*>(pro_l + 64 + chunk * 8);
+                const half8_t s = *reinterpret_cast<const half8_t*>(pro_l + kk * 16 + frag_half * 8);
+                const half8_t b = *reinterpret_cast<const half8_t*>(pro_l + K + kk * 16 + frag_half * 8);
                 const half8_t z = {};
                 bf = __builtin_elementwise_max(bf * s + b, z);
             }
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = x[e] + rr[e];       // fp16 Add, like the reference graph
             }
-            if (m < a.m_total) *reinterpret_cast<uint4*>(a.out + (size_t)m * 256 + ch * 8) = v;
+            if (m < a.m_total) *reinterpret_cast<uint4*>(a.out + (size_t)m * ldo + ch * 8) = v;
             if constexpr (MODE2 == 2) {
                 // next unit's pre-activation (fp16 BN + ReLU) goes back into the tile for the second GEMM
                 const half8_t z = {};
@@ -294,22 +316,23 @@ static bool pw_enabled() {
 // mode: 0 plain, 1 shortcut + conv1 pair (desc.c_out = 320 = 256 + 64 concatenated rows), 2 conv3 + next conv1
 bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
     if (!pw_enabled()) return false;
-    const int c_out = mode == 1 ? 320 : 256;
-    if (!(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_top == 0 && d.pad_left == 0 && d.c_in == 64 &&
-          d.in_pix_stride == 64 && d.c_out == c_out && d.h_in == d.h_out && d.w_in == d.w_out && d.relu == 0 &&
-          d.out_dtype == METRO_F16 && d.in_dtype == METRO_F16))
+    if (!(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_top == 0 && d.pad_left == 0 && d.in_pix_stride == d.c_in &&
+          d.h_in == d.h_out && d.w_in == d.w_out && d.relu == 0 && d.out_dtype == METRO_F16 && d.in_dtype == METRO_F16))
         return false;
     if (d.has_residual && !(d.res_stride == 1 && d.res_offset == 0 && d.res_h == d.h_out && d.res_w == d.w_out)) return false;
     // built combinations: prologue without shortcut (projection shortcut, pair) / shortcut without prologue (conv3)
-    if (mode == 1) return d.has_prologue && !d.has_residual;
-    if (mode == 2) return !d.has_prologue && d.has_residual;
-    return (d.has_prologue != 0) != (d.has_residual != 0);
+    if (mode == 1) return d.c_in == 64 && d.c_out == 320 && d.has_prologue && !d.has_residual;
+    if (mode == 2) return d.c_in == 64 && d.c_out == 256 && !d.has_prologue && d.has_residual;
+    if (d.c_in == 64 && d.c_out == 256) return (d.has_prologue != 0) != (d.has_residual != 0);
+    // block2's conv3 (128 -> 512 + shortcut): two 256-channel halves
+    static const int k128 = pw_env_int("METRO_PW128", 1);
+    return k128 && d.c_in == 128 && d.c_out == 512 && !d.has_prologue && d.has_residual;
 }
 
-template <bool PRO, bool RES, int MODE2>
+template <int K, bool PRO, bool RES, int MODE2>
 static int launch_pw(const Pw64Args& a, hipStream_t stream) {
-    auto kern = conv_pw64_kernel<PRO, RES, MODE2>;
-    constexpr int lds = pw::lds_bytes<RES, MODE2>();
+    auto kern = conv_pw64_kernel<K, PRO, RES, MODE2>;
+    constexpr int lds = pw::lds_bytes<K, RES, MODE2>();
     static int grid_cap = 0;
     if (grid_cap == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -323,7 +346,9 @@ static int launch_pw(const Pw64Args& a, hipStream_t stream) {
         if (cap > 0 && cap < occ) occ = cap;
         grid_cap = cus * occ;
     }
-    const int grid = a.n_tiles < grid_cap ? a.n_tiles : grid_cap;
+    const int halves = a.c_out / 256;
+    int grid = a.n_tiles * halves < grid_cap ? a.n_tiles * halves : grid_cap;
+    grid -= grid % halves;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(pw::NT), lds, stream, a);
     return launch_status("conv_pw64");
 }
@@ -348,18 +373,20 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
     a.w2 = nullptr; a.bias2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out2 = nullptr;
     a.m_total = d.n * d.h_out * d.w_out;
     a.n_tiles = (a.m_total + pw::TN - 1) / pw::TN;
+    a.c_out = mode == 1 ? 256 : d.c_out;
     if (mode == 1) {
         a.w2 = a.w + 256 * 64; a.bias2 = bias + 256; a.out2 = static_cast<half_t*>(split->out2);
-        return launch_pw<true, false, 1>(a, stream);
+        return launch_pw<64, true, false, 1>(a, stream);
     }
     if (mode == 2) {
         a.w2 = static_cast<const half_t*>(f2->w2); a.bias2 = f2->bias2;
         a.scale2 = static_cast<const half_t*>(f2->scale2); a.shift2 = static_cast<const half_t*>(f2->shift2);
         a.out2 = static_cast<half_t*>(f2->out2);
-        return launch_pw<false, true, 2>(a, stream);
+        return launch_pw<64, false, true, 2>(a, stream);
     }
-    if (d.has_prologue) return launch_pw<true, false, 0>(a, stream);
-    return launch_pw<false, true, 0>(a, stream);
+    if (d.c_in == 128) return launch_pw<128, false, true, 0>(a, stream);
+    if (d.has_prologue) return launch_pw<64, true, false, 0>(a, stream);
+    return launch_pw<64, false, true, 0>(a, stream);
 }
 
 }  // namespace metro
