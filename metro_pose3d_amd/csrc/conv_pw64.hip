@@ -1,4 +1,4 @@
-// Persistent, software-pipelined 1x1 convolution for block1's 64-channel tensors (c_in = 64, c_out = 256).
+// Persistent, weight-stationary, software-pipelined 1x1 convolution (c_in <= 512, c_out in 256-channel slabs).
 //
 // These layers (projection shortcut, conv1, conv3 of resnet_v2 block1 at 64x64: reference resnet_v2.py:120-138)
 // move 170-340 MB per launch against 2-17 GFLOP: they are pure memory streams.  The tiled kernel
@@ -51,22 +51,33 @@ struct Pw64Args {
 };
 
 namespace pw {
-constexpr int TN = 64;                         // pixels per tile
 constexpr int NW = 8, NT = 512;
 constexpr int OUT_ROW = 256 * 2 + 16;          // padded rows of the [pixel][cout] tile
-constexpr int OUT_BYTES = TN * OUT_ROW;
-constexpr int RES_BYTES = TN * 512;
-constexpr int PAR_BYTES = 1024 + 256 + 256 + 256;   // bias[256] f32 | bias2[64] f32 | pro scale[K<=128] | pro shift fp16
-template <int K>
+// WM = waves along the 256 output channels: 4 -> wave tile 64 couts x 32 pixels, 64-pixel tiles (weights K/2
+// VGPRs per lane: K <= 128); 8 -> wave tile 32 couts x 32 pixels, 32-pixel tiles (K/4 VGPRs: K <= 512)
+template <int K, int WM>
 struct Lay {
-    static constexpr int X_BYTES = TN * K * 2;     // one input tile: K/64 swizzled slices of 64 rows x 64 fp16
-    static constexpr int X_OFF = 0;                // 2 buffers
+    static constexpr int WN = NW / WM;
+    static constexpr int NI = 8 / WM;               // 32-row MFMA tiles per wave
+    static constexpr int TN = 32 * WN;              // pixels per tile
+    static constexpr int KS = K / 64;               // input tile = KS swizzled slices of TN rows x 64 fp16
+    static constexpr int SL_BYTES = TN * 128;
+    static constexpr int X_BYTES = KS * SL_BYTES;
+    static constexpr int XI = X_BYTES / 1024 / NW;  // input DMA instructions per wave per tile
+    static constexpr int RI = TN / 16;              // row-wise iterations = shortcut DMA instructions = stores per wave
+    static constexpr int OUT_BYTES = TN * OUT_ROW;
+    static constexpr int RES_BYTES = TN * 512;
+    static constexpr int PAR_BYTES = 1024 + 256 + 4 * K;   // bias[256] f32 | bias2[64] f32 | pro scale[K] | pro shift[K] fp16
+    static constexpr int X_OFF = 0;                 // 2 buffers
     static constexpr int OUT_OFF = X_OFF + 2 * X_BYTES;
     static constexpr int PAR_OFF = OUT_OFF + OUT_BYTES;
     static constexpr int RES_OFF = PAR_OFF + PAR_BYTES;   // 2 buffers (RES)
+    static_assert(X_BYTES % (1024 * NW) == 0, "input tile must split evenly over the waves");
 };
-template <int K, bool RES, int MODE2>
-constexpr int lds_bytes() { return Lay<K>::RES_OFF + (RES ? 2 * RES_BYTES : 0) + (MODE2 == 2 ? 64 * 256 * 2 : 0); }
+template <int K, int WM, bool RES, int MODE2>
+constexpr int lds_bytes() {
+    return Lay<K, WM>::RES_OFF + (RES ? 2 * Lay<K, WM>::RES_BYTES : 0) + (MODE2 == 2 ? 64 * 256 * 2 : 0);
+}
 }  // namespace pw
 
 __device__ __forceinline__ int pw_swz(int row) { return (row >> 1) & 7; }
@@ -87,14 +98,15 @@ __device__ __forceinline__ void pw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int K, bool PRO, bool RES, int MODE2>
+template <int K, int WM, bool PRO, bool RES, int MODE2>
 __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     using namespace pw;
-    static_assert(K == 64 || K == 128, "weights must fit the register file as MFMA fragments");
-    static_assert(MODE2 == 0 || K == 64, "second outputs are block1 shapes");
-    constexpr int KK = K / 16, KS = K / 64;
-    constexpr int X_BYTES = Lay<K>::X_BYTES, X_OFF = Lay<K>::X_OFF, OUT_OFF = Lay<K>::OUT_OFF, PAR_OFF = Lay<K>::PAR_OFF,
-                  RES_OFF = Lay<K>::RES_OFF;
+    using L = Lay<K, WM>;
+    static_assert((WM == 4 && K <= 128) || (WM == 8 && K <= 512), "weights must fit the register file as MFMA fragments");
+    static_assert(MODE2 == 0 || (K == 64 && WM == 4), "second outputs are block1 shapes");
+    constexpr int KK = K / 16, WN = L::WN, NI = L::NI, TN = L::TN, XI = L::XI, RI = L::RI;
+    constexpr int X_BYTES = L::X_BYTES, X_OFF = L::X_OFF, OUT_OFF = L::OUT_OFF, PAR_OFF = L::PAR_OFF, RES_OFF = L::RES_OFF,
+                  RES_BYTES = L::RES_BYTES, SL_BYTES = L::SL_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void_t;
     const unsigned smem_base = (unsigned)(size_t)(lds_void_t*)smem;
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;            // wave tile: couts wm*64..+64, pixels wn*32..+32
+    const int wm = wave / WN, wn = wave % WN;           // wave tile: couts wm*32*NI.., pixels wn*32..+32
     const int frag_row = lane & 31, frag_half = lane >> 5;
     // 256-channel halves of wider outputs go to different blocks (the weights are register-resident)
     const int halves = a.c_out >> 8;
@@ -119,12 +131,12 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page_pw);
 
     // ---- launch-resident operands ------------------------------------------------------------
-    half8_t wf[2][KK];
+    half8_t wf[NI][KK];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
-            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(wm * 64 + i * 32 + frag_row) * K + kk * 16 + frag_half * 8);
+            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)((wm * NI + i) * 32 + frag_row) * K + kk * 16 + frag_half * 8);
     half8_t w2f[4];
     if constexpr (MODE2 == 1) {
         if (wave < 4) {
@@ -156,21 +168,27 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     }
 
     // ---- per-lane DMA coordinates ------------------------------------------------------------
-    // input tile = K/64 slices [64 rows][64 k] (128-byte rows, chunk-swizzled); slice j of this wave's 8 rows
-    const int xrow = wave * 8 + (lane >> 3);                       // input row this lane fetches 16 bytes of
-    const int xoff = xrow * K + (((lane & 7) ^ pw_swz(xrow)) * 8);
+    // input tile = K/64 slices [TN rows][64 k] (128-byte rows, chunk-swizzled); DMA instruction q = i*8 + wave
+    // fills 8 rows of slice q / (TN/8)
+    int xrow[XI], xoff[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int q = i * NW + wave;
+        xrow[i] = (q % (TN / 8)) * 8 + (lane >> 3);
+        xoff[i] = xrow[i] * K + (q / (TN / 8)) * 64 + (((lane & 7) ^ pw_swz(xrow[i])) * 8);
+    }
     auto issue_tile = [&](int tile, int buf) {
         const int m0 = tile * TN;
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            const half_t* xs = (m0 + xrow < a.m_total) ? a.in + (size_t)m0 * K + xoff + j * 64 : zero;
-            pw_dma16(xs, __builtin_amdgcn_readfirstlane(smem_base + X_OFF + buf * X_BYTES + j * 8192 + wave * 1024));
+        for (int i = 0; i < XI; ++i) {
+            const half_t* xs = (m0 + xrow[i] < a.m_total) ? a.in + (size_t)m0 * K + xoff[i] : zero;
+            pw_dma16(xs, __builtin_amdgcn_readfirstlane(smem_base + X_OFF + buf * X_BYTES + (i * NW + wave) * 1024));
         }
         if constexpr (RES) {
             // shortcut rows: chunk c = it*512 + tid (row c/32, 16-byte column c%32) lands at c*16, i.e. every
             // wave later reads back exactly the bytes it requested
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < RI; ++it) {
                 const int c = it * NT + tid;
                 const half_t* rs = (m0 + (c >> 5) < a.m_total) ? a.residual + (size_t)(m0 + (c >> 5)) * ldo + (c & 31) * 8 : zero;
                 pw_dma16(rs, __builtin_amdgcn_readfirstlane(smem_base + RES_OFF + buf * RES_BYTES + it * 8192 + wave * 1024));
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     };
 
     issue_tile(t, 0);
-    // stores of one tile per wave (all younger than the next tile's loads): 4 row-wise (+4 second-output)
+    // stores of one tile per wave (all younger than the next tile's loads): RI row-wise (+4 second-output)
     const bool two = MODE2 != 0 && wave < 4;
     bool prev_full = false;
     for (int it = 0;; ++it, t += G) {
@@ -187,30 +205,34 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         const int m0 = t * TN;
         // ---- the tile's loads have landed (for this wave), then for every wave -----------------
         if (it == 0 || !prev_full) pw_wait_vm<0>();
-        else if (two) pw_wait_vm<8>();
-        else pw_wait_vm<4>();
+        else if (two) pw_wait_vm<RI + 4>();
+        else pw_wait_vm<RI>();
         pw_barrier();
         if (t + G < a.n_tiles) issue_tile(t + G, buf ^ 1);
         prev_full = m0 + TN <= a.m_total;
 
         // ---- GEMM 1: [256 x 64] x [64 x 64 pixels] ---------------------------------------------
-        floatx16 acc[2], acc2;
+        floatx16 acc[NI], acc2;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; acc2[e] = 0.f; }
+        for (int e = 0; e < 16; ++e) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[i][e] = 0.f;
+            acc2[e] = 0.f;
+        }
         const char* xl = smem + X_OFF + buf * X_BYTES;
         const int brow = wn * 32 + frag_row;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const int chunk = (kk & 3) * 2 + frag_half;
-            half8_t bf = *reinterpret_cast<const half8_t*>(xl + (kk >> 2) * 8192 + brow * 128 + ((chunk ^ pw_swz(brow)) << 4));
+            half8_t bf = *reinterpret_cast<const half8_t*>(xl + (kk >> 2) * SL_BYTES + brow * 128 + ((chunk ^ pw_swz(brow)) << 4));
             if constexpr (PRO) {
                 const half8_t s = *reinterpret_cast<const half8_t*>(pro_l + kk * 16 + frag_half * 8);
                 const half8_t b = *reinterpret_cast<const half8_t*>(pro_l + K + kk * 16 + frag_half * 8);
                 const half8_t z = {};
                 bf = __builtin_elementwise_max(bf * s + b, z);
             }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][kk], bf, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][kk], bf, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][kk], bf, acc[i], 0, 0, 0);
             if constexpr (MODE2 == 1) {
                 if (wave < 4) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[kk], bf, acc2, 0, 0, 0);
             }
@@ -235,10 +257,10 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         // ---- accumulators (+bias) -> LDS tile [pixel][cout] fp16 -------------------------------
         char* ol = smem + OUT_OFF;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = (wm * 2 + i) * 32 + 8 * q + 4 * frag_half;
+                const int col = (wm * NI + i) * 32 + 8 * q + 4 * frag_half;
                 const floatx4 bv = *reinterpret_cast<const floatx4*>(bias_l + col);
                 half4_t hv;
 #pragma unroll
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         // ---- row-wise: 16 bytes per lane, + shortcut, full-row stores ---------------------------
         const char* rl = smem + RES_OFF + buf * RES_BYTES;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < RI; ++r) {
             const int idx = tid + r * NT;
             const int prow = idx >> 5;
             const int m = m0 + prow;
@@ -324,15 +346,17 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
     if (mode == 1) return d.c_in == 64 && d.c_out == 320 && d.has_prologue && !d.has_residual;
     if (mode == 2) return d.c_in == 64 && d.c_out == 256 && !d.has_prologue && d.has_residual;
     if (d.c_in == 64 && d.c_out == 256) return (d.has_prologue != 0) != (d.has_residual != 0);
-    // block2's conv3 (128 -> 512 + shortcut): two 256-channel halves
-    static const int k128 = pw_env_int("METRO_PW128", 1);
-    return k128 && d.c_in == 128 && d.c_out == 512 && !d.has_prologue && d.has_residual;
+    // conv3 (+ shortcut) of blocks 2-4: c_out = 4 * c_in in 256-channel slabs (METRO_PW_MAXK caps c_in for A/B runs)
+    static const int maxk = pw_env_int("METRO_PW_MAXK", 512);
+    return (d.c_in == 128 || d.c_in == 256 || d.c_in == 512) && d.c_in <= maxk && d.c_out == 4 * d.c_in &&
+           !d.has_prologue && d.has_residual;
 }
 
-template <int K, bool PRO, bool RES, int MODE2>
-static int launch_pw(const Pw64Args& a, hipStream_t stream) {
-    auto kern = conv_pw64_kernel<K, PRO, RES, MODE2>;
-    constexpr int lds = pw::lds_bytes<K, RES, MODE2>();
+template <int K, int WM, bool PRO, bool RES, int MODE2>
+static int launch_pw(Pw64Args a, hipStream_t stream) {
+    auto kern = conv_pw64_kernel<K, WM, PRO, RES, MODE2>;
+    constexpr int lds = pw::lds_bytes<K, WM, RES, MODE2>();
+    a.n_tiles = (a.m_total + pw::Lay<K, WM>::TN - 1) / pw::Lay<K, WM>::TN;
     static int grid_cap = 0;
     if (grid_cap == 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -372,21 +396,23 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
     a.out = static_cast<half_t*>(out);
     a.w2 = nullptr; a.bias2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out2 = nullptr;
     a.m_total = d.n * d.h_out * d.w_out;
-    a.n_tiles = (a.m_total + pw::TN - 1) / pw::TN;
+    a.n_tiles = 0;
     a.c_out = mode == 1 ? 256 : d.c_out;
     if (mode == 1) {
         a.w2 = a.w + 256 * 64; a.bias2 = bias + 256; a.out2 = static_cast<half_t*>(split->out2);
-        return launch_pw<64, true, false, 1>(a, stream);
+        return launch_pw<64, 4, true, false, 1>(a, stream);
     }
     if (mode == 2) {
         a.w2 = static_cast<const half_t*>(f2->w2); a.bias2 = f2->bias2;
         a.scale2 = static_cast<const half_t*>(f2->scale2); a.shift2 = static_cast<const half_t*>(f2->shift2);
         a.out2 = static_cast<half_t*>(f2->out2);
-        return launch_pw<64, false, true, 2>(a, stream);
+        return launch_pw<64, 4, false, true, 2>(a, stream);
     }
-    if (d.c_in == 128) return launch_pw<128, false, true, 0>(a, stream);
-    if (d.has_prologue) return launch_pw<64, true, false, 0>(a, stream);
-    return launch_pw<64, false, true, 0>(a, stream);
+    if (d.c_in == 512) return launch_pw<512, 8, false, true, 0>(a, stream);
+    if (d.c_in == 256) return launch_pw<256, 8, false, true, 0>(a, stream);
+    if (d.c_in == 128) return launch_pw<128, 4, false, true, 0>(a, stream);
+    if (d.has_prologue) return launch_pw<64, 4, true, false, 0>(a, stream);
+    return launch_pw<64, 4, false, true, 0>(a, stream);
 }
 
 }  // namespace metro

@@ -25,6 +25,10 @@ CONV_CASES = [
     ('1x1_pw64_many_tiles', 25, 64, 64, 256, 1, 1, 1, 0, 64),
     ('1x1_pw128_halves_ragged', 3, 7, 128, 512, 1, 1, 1, 0, 7),
     ('1x1_pw128_many_tiles', 25, 32, 128, 512, 1, 1, 1, 0, 32),
+    ('1x1_pw256_slabs_ragged', 3, 7, 256, 1024, 1, 1, 1, 0, 7),
+    ('1x1_pw256_many_tiles', 40, 16, 256, 1024, 1, 1, 1, 0, 16),
+    ('1x1_pw512_slabs_ragged', 3, 7, 512, 2048, 1, 1, 1, 0, 7),
+    ('1x1_pw512_many_tiles', 40, 16, 512, 2048, 1, 1, 1, 0, 16),
     ('1x1_head136', 2, 16, 128, 136, 1, 1, 1, 0, 16),
     ('1x1_cin_tail', 2, 8, 24, 64, 1, 1, 1, 0, 8),
     ('3x3_s1', 2, 16, 64, 64, 3, 1, 1, 1, 16),
