@@ -105,6 +105,11 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode);
 int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* pro_scale,
                      const void* pro_shift, const void* residual, void* out, hipStream_t stream,
                      const ConvSplit* split, const ConvFuse2* fuse2);
+// stem 7x7/2 conv + zero-padded 3x3/2 max-pool in one persistent kernel (stem_pool_f16.hip); input is the
+// bordered 4-channel fp16 image of launch_prep_input_f16, weights packed [64][7][8][4]
+bool stem_pool_f16_supported(int side, int base_width);
+int launch_stem_pool_f16(const void* prepped, const void* w, const float* bias, void* out, int n, int side,
+                         hipStream_t stream);
 // 3x3 stride-1 convs with tap reuse from an LDS-resident activation slab
 bool conv3x3_slab_supported(const MetroConvDesc& d);
 int launch_conv3x3_slab(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out,

@@ -71,6 +71,7 @@ struct Layer {
     int split, c_out2, relu2, out2_slot;
     // conv3 of unit u + conv1 of unit u+1 (ConvFuse2): parameter indices of the second GEMM, -1 = none
     int f2_w, f2_bias, f2_scale, f2_shift, f2_c2;
+    int stem_pool;        // stem conv + max-pool in one launch (the layer's output is the pooled tensor)
 };
 
 }  // namespace
@@ -277,6 +278,7 @@ int build_plan(MetroPlan* p) {
     // ---- root block: conv1 7x7/2 with explicit pad 3 (+bias, no BN, no ReLU), pool1 ----------
     // reference resnet_v2.py:219-224, resnet_utils.py:125-135,177-185
     const int s2 = (side + 6 - 7) / 2 + 1;   // 128
+    bool fused_stem_pool = false;
     if (fast) {
         Layer L;
         memset(&L, 0, sizeof(L));
@@ -307,15 +309,27 @@ int build_plan(MetroPlan* p) {
         S.p_bias = B.add_param("conv1/bias", METRO_PARAM_BIAS, cv, "", METRO_F32, bw, 1, 1, 1, 1, 1);
         S.p_scale = S.p_shift = -1;
         S.in_slot = S_PREP; S.out_slot = S_STEM; S.res_slot = S_NONE;
-        B.need(S_STEM, (int64_t)s2 * s2 * bw * aes);
-        B.fill_info(S, "conv1", 2.0 * s2 * s2 * bw * 7 * 7 * 3);
+        if (stem_pool_f16_supported(side, bw)) {
+            // reference resnet_v2.py:219-224: the pooled tensor is the only thing block1 reads
+            fused_stem_pool = true;
+            S.stem_pool = 1;
+            S.out_slot = S_X0;
+            const int s4f = (s2 + 2 - 3) / 2 + 1;
+            B.need(S_X0, (int64_t)s4f * s4f * bw * aes);
+            B.fill_info(S, "conv1+pool1", 2.0 * s2 * s2 * bw * 7 * 7 * 3);
+            S.info.h_out = S.info.w_out = s4f;
+            S.cd.h_out = S.cd.w_out = s4f;        // shape of the stored tensor (forward_upto, out_bytes_per_image)
+        } else {
+            B.need(S_STEM, (int64_t)s2 * s2 * bw * aes);
+            B.fill_info(S, "conv1", 2.0 * s2 * s2 * bw * 7 * 7 * 3);
+        }
         p->layers.push_back(S);
     } else {
         B.add_conv("conv1", "conv1", "", "", S_IMAGES, S_STEM, S_NONE, side, 3, s2, bw, 7, 2, 1, 3,
                    false, 0, 1, 0, adt, METRO_F32);
     }
     const int s4 = (s2 + 2 - 3) / 2 + 1;     // 64
-    {
+    if (!fused_stem_pool) {
         Layer L;
         memset(&L, 0, sizeof(L));
         L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
@@ -503,7 +517,10 @@ int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_
             case LK_CONV: {
                 MetroConvDesc cd = L.cd;
                 cd.n = n;
-                if (p->fast && L.split > 0) {
+                if (p->fast && L.stem_pool) {
+                    st = launch_stem_pool_f16(slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
+                                              slot_ptr(L.out_slot), n, p->spec.proc_side, stream);
+                } else if (p->fast && L.split > 0) {
                     ConvSplit sp;
                     sp.split = L.split; sp.c_out2 = L.c_out2; sp.relu2 = L.relu2; sp.out2 = slot_ptr(L.out2_slot);
                     st = launch_conv_f16_dma(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),

@@ -1,0 +1,233 @@
+// Stem 7x7/2 convolution + 3x3/2 zero-padded max-pool in one persistent kernel (fp16 mode, base width 64).
+//
+// reference: resnet_v2.py:219-224 (conv2d_same 7x7 stride 2 with biases, no activation) followed by
+// resnet_utils.max_pool2d_same (resnet_utils.py:138-185: explicit ZERO padding, then VALID 3x3/2 pooling).
+// Run separately these are 76 + 36 us at batch 64: the 134 MB conv output is written and read back just to be
+// reduced 4:1.  Here a block owns an 8x8 patch of POOLED pixels:
+//   * the 39x40-pixel window of the bordered 4-channel fp16 image (prep_input_f16) it needs is LDS-DMA'd,
+//     the next patch's window while the current one is computed;
+//   * the 17x17 conv pixels under the patch (one halo row/column: 13 % recompute) are an implicit GEMM
+//     [64 couts x 224] x [224 x 289 pixels] whose B fragments are read straight from the window (tap row r =
+//     8 pixels x 4 channels = 32 contiguous fp16, the 8th pixel and 4th channel meet zero weights);
+//   * the weights stay in registers as MFMA A-fragments for the whole launch (112 VGPRs per lane);
+//   * conv + bias goes to LDS as fp16 (the value the separate kernels would have stored), the pool takes the
+//     max of the 3x3 window with out-of-image conv positions contributing 0, and only pooled rows are stored.
+#include <cstdlib>
+
+#include "metro_common.h"
+
+namespace metro {
+
+typedef _Float16 half_t;
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page_sp[4];   // zero-initialised
+
+namespace sp {
+constexpr int NT = 256, NW = 4;
+constexpr int PP = 8;                         // pooled patch side
+constexpr int CP = 2 * PP + 1;                // conv pixels per patch side (17)
+constexpr int CPIX = CP * CP;                 // 289
+constexpr int MT = (CPIX + 31) / 32;          // 10 MFMA pixel tiles
+constexpr int WIN_R = 2 * (CP - 1) + 7;       // 39 window rows
+constexpr int WIN_C = 2 * (CP - 1) + 8;       // 40 window columns (pixels of 4 channels = 8 bytes)
+constexpr int WIN_ROW_BYTES = WIN_C * 8;      // 320
+constexpr int WIN_CHUNKS = WIN_R * WIN_C / 2; // 780 16-byte chunks
+constexpr int WIN_INSTR = (WIN_CHUNKS + 63) / 64;     // 13 DMA wave-instructions
+constexpr int WIN_BYTES = WIN_INSTR * 1024;
+constexpr int CONV_ROW = 64 * 2 + 16;         // padded rows of the [conv pixel][cout] tile
+constexpr int CONV_BYTES = CPIX * CONV_ROW;
+constexpr int WIN_OFF = 0;                    // 2 buffers
+constexpr int CONV_OFF = WIN_OFF + 2 * WIN_BYTES;
+constexpr int BIAS_OFF = CONV_OFF + ((CONV_BYTES + 15) / 16) * 16;
+constexpr int LDS_BYTES = BIAS_OFF + 256;
+constexpr int KK = 14;                        // 7 tap rows x 2 k-steps of 16
+}  // namespace sp
+
+struct StemPoolArgs {
+    const half_t* img;     // [n][side+6][side+8][4] fp16 (prep_input_f16)
+    const half_t* w;       // [64][7][8][4] fp16
+    const float* bias;     // [64]
+    half_t* out;           // [n][side/4][side/4][64]
+    int n, side;           // side % 32 == 0
+    int n_patches;
+};
+
+__device__ __forceinline__ void sp_dma16(const void* gsrc, unsigned lds_addr) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(gsrc), "s"(lds_addr));
+}
+template <int N>
+__device__ __forceinline__ void sp_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void sp_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a) {
+    using namespace sp;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    const unsigned smem_base = (unsigned)(size_t)(lds_void_t*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+    const int G = gridDim.x;
+    int p = blockIdx.x;
+    if (p >= a.n_patches) return;
+    const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page_sp);
+    const int hp = a.side + 6, wp = a.side + 8;          // bordered image
+    const int ps = a.side / 4;                           // pooled side
+    const int ppr = ps / PP;                             // patches per row
+    const int cs = a.side / 2;                           // conv side
+
+    // ---- launch-resident weights: both 32-cout tiles, 14 k-steps ------------------------------
+    half8_t wf[2][KK];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(i * 32 + frag_row) * 224 + kk * 16 + frag_half * 8);
+    float* bias_l = reinterpret_cast<float*>(smem + BIAS_OFF);
+    if (tid < 64) bias_l[tid] = a.bias[tid];
+
+    // window chunk c = q*64 + lane (q = wave + 4*i): window row c / 20, pixel pair c % 20
+    auto issue_window = [&](int patch, int buf) {
+        const int img = patch / (ppr * ppr);
+        const int rem = patch - img * ppr * ppr;
+        const int r0 = 4 * PP * (rem / ppr) - 2, c0 = 4 * PP * (rem % ppr) - 2;   // window origin in the bordered image
+        const half_t* base = a.img + (size_t)img * hp * wp * 4;
+#pragma unroll
+        for (int i = 0; i < (WIN_INSTR + NW - 1) / NW; ++i) {
+            const int q = wave + NW * i;
+            if (q < WIN_INSTR) {
+                const int c = q * 64 + lane;
+                const int wr = c / (WIN_C / 2), wc = (c - wr * (WIN_C / 2)) * 2;
+                const int y = r0 + wr, x = c0 + wc;
+                const bool ok = c < WIN_CHUNKS && (unsigned)y < (unsigned)hp && (unsigned)x < (unsigned)wp;
+                sp_dma16(ok ? base + ((size_t)y * wp + x) * 4 : zero,
+                         __builtin_amdgcn_readfirstlane(smem_base + WIN_OFF + buf * WIN_BYTES + q * 1024));
+            }
+        }
+    };
+
+    issue_window(p, 0);
+    for (int it = 0;; ++it, p += G) {
+        const int buf = it & 1;
+        // the window has landed (the only younger VMEM operations are the previous patch's 2 pooled stores)
+        if (it == 0) sp_wait_vm<0>();
+        else sp_wait_vm<2>();
+        sp_barrier();
+        if (p + G < a.n_patches) issue_window(p + G, buf ^ 1);
+
+        const int img = p / (ppr * ppr);
+        const int rem = p - img * ppr * ppr;
+        const int py0 = PP * (rem / ppr), px0 = PP * (rem % ppr);
+        const char* wl = smem + WIN_OFF + buf * WIN_BYTES;
+        char* cl = smem + CONV_OFF;
+        // ---- conv: pixel tiles mt = wave, wave+4, wave+8 -----------------------------------------
+#pragma unroll 1
+        for (int mt = wave; mt < MT; mt += NW) {
+            const int m = mt * 32 + frag_row;
+            const int mc = m < CPIX ? m : CPIX - 1;
+            const int cyl = mc / CP, cxl = mc - cyl * CP;
+            const char* bp = wl + (2 * cyl) * WIN_ROW_BYTES + (2 * cxl) * 8 + frag_half * 16;
+            floatx16 acc[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const half8_t bf = *reinterpret_cast<const half8_t*>(bp + (kk >> 1) * WIN_ROW_BYTES + (kk & 1) * 32);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][kk], bf, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][kk], bf, acc[1], 0, 0, 0);
+            }
+            if (m < CPIX) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = i * 32 + 8 * q + 4 * frag_half;
+                        const floatx4 bv = *reinterpret_cast<const floatx4*>(bias_l + co);
+                        half4_t hv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[e] = (half_t)(acc[i][4 * q + e] + bv[e]);
+                        *reinterpret_cast<half4_t*>(cl + m * CONV_ROW + co * 2) = hv;
+                    }
+            }
+        }
+        sp_barrier();
+        // ---- pool: (pooled pixel, 8-channel chunk) items, zero where the conv position is outside -------
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int item = tid + r * NT;
+            const int c8 = item & 7, pp = item >> 3;
+            const int ppy = pp >> 3, ppx = pp & 7;
+            half8_t best = {};
+            bool first = true;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int cy = 2 * (py0 + ppy) - 1 + dy;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cx = 2 * (px0 + ppx) - 1 + dx;
+                    half8_t v = *reinterpret_cast<const half8_t*>(cl + ((2 * ppy + dy) * CP + 2 * ppx + dx) * CONV_ROW + c8 * 16);
+                    const half8_t z = {};
+                    if (!((unsigned)cy < (unsigned)cs && (unsigned)cx < (unsigned)cs)) v = z;
+                    best = first ? v : __builtin_elementwise_max(best, v);
+                    first = false;
+                }
+            }
+            *reinterpret_cast<half8_t*>(a.out + (((size_t)img * ps + py0 + ppy) * ps + px0 + ppx) * 64 + c8 * 8) = best;
+        }
+        if (p + G >= a.n_patches) break;
+    }
+}
+
+static int sp_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+bool stem_pool_f16_supported(int side, int base_width) {
+    static const int enabled = sp_env_int("METRO_STEM_POOL", 1);
+    return enabled && base_width == 64 && side % 32 == 0 && side >= 32;
+}
+
+int launch_stem_pool_f16(const void* prepped, const void* w, const float* bias, void* out, int n, int side,
+                         hipStream_t stream) {
+    if (!stem_pool_f16_supported(side, 64)) { set_error("stem_pool_f16: unsupported shape (side %d)", side); return METRO_ERR_INVALID_ARG; }
+    StemPoolArgs a;
+    a.img = static_cast<const half_t*>(prepped);
+    a.w = static_cast<const half_t*>(w);
+    a.bias = bias;
+    a.out = static_cast<half_t*>(out);
+    a.n = n; a.side = side;
+    const int ppr = side / 4 / sp::PP;
+    a.n_patches = n * ppr * ppr;
+    static int grid_cap = 0;
+    if (grid_cap == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_f16_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, sp::LDS_BYTES);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute(stem_pool): %s", hipGetErrorString(e)); return METRO_ERR_HIP; }
+        int dev = 0, cus = 0, occ = 0;
+        METRO_HIP_CHECK(hipGetDevice(&dev));
+        METRO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        METRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, stem_pool_f16_kernel, sp::NT, sp::LDS_BYTES));
+        if (occ < 1) occ = 1;
+        grid_cap = cus * occ;
+    }
+    const int grid = a.n_patches < grid_cap ? a.n_patches : grid_cap;
+    hipLaunchKernelGGL(stem_pool_f16_kernel, dim3(grid), dim3(sp::NT), sp::LDS_BYTES, stream, a);
+    return launch_status("stem_pool_f16");
+}
+
+}  // namespace metro

@@ -54,7 +54,7 @@ def test_toy_layerwise(cuda, spec):
         eng = Engine(spec, params, prec, max_batch=2, device=cuda)
         for i, li in enumerate(eng.layer_infos()):
             name = li.name.decode()
-            key = {'logits': 'logits', 'conv1': 'conv1', 'pool1': 'pool1'}.get(name)
+            key = {'logits': 'logits', 'conv1': 'conv1', 'pool1': 'pool1', 'conv1+pool1': 'pool1'}.get(name)
             if key is None and (name.endswith('/conv3') or '/conv3+' in name):
                 key = name.split('/conv3')[0]                # unit output = shortcut + conv3
             elif key is None and name.endswith(('/conv1', '/conv2')):
@@ -65,6 +65,31 @@ def test_toy_layerwise(cuda, spec):
             ref = col[key].permute(0, 2, 3, 1).numpy()
             err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
             assert err <= rel, (prec, name, err)
+
+
+def test_fused_stem_conv_pool(cuda):
+    """Stem 7x7/2 conv + zero-padded 3x3/2 max-pool in one persistent launch (full base width): against a
+    torch fp64 restatement on the same fp16-rounded operands (reference resnet_v2.py:219-224,
+    resnet_utils.py:138-185).  9 images = 576 patches: more than the resident blocks, so blocks walk several
+    patches through their double-buffered windows."""
+    spec = ModelSpec(50, 32, 'h36m')
+    params, images = _setup(spec, 9)
+    x = torch.from_numpy(images).to(cuda)
+    eng = Engine(spec, params, 'f16', max_batch=9, device=cuda)
+    names = [li.name.decode() for li in eng.layer_infos()]
+    assert 'conv1+pool1' in names and 'pool1' not in names
+    got = eng.forward_upto(x, names.index('conv1+pool1')).cpu().double()
+    root = 'MainPart/resnet_v2_50/conv1'
+    w = torch.from_numpy(params[root + '/weights'].astype(np.float16).astype(np.float64)).permute(3, 2, 0, 1)   # HWIO -> OIHW
+    b = torch.from_numpy(params[root + '/biases'].astype(np.float32).astype(np.float64))
+    xi = torch.from_numpy(images.astype(np.float16).astype(np.float64)).permute(0, 3, 1, 2)
+    conv = torch.nn.functional.conv2d(torch.nn.functional.pad(xi, (3, 3, 3, 3)), w, b, stride=2)
+    conv = conv.half().double()                                   # the fp16 tensor the unfused path stores
+    want = torch.nn.functional.max_pool2d(torch.nn.functional.pad(conv, (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1)
+    assert got.shape == want.shape == (9, 64, 64, 64)
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    assert err <= 2e-3, err                                       # one fp16 ulp of the largest value
+    assert (got == want).double().mean().item() > 0.98           # almost all elements bit-identical
 
 
 def test_fused_launch_second_outputs(cuda):
