@@ -13,6 +13,7 @@
 //   * conv + bias goes to LDS as fp16 (the value the separate kernels would have stored), the pool takes the
 //     max of the 3x3 window with out-of-image conv positions contributing 0, and only pooled rows are stored.
 #include <cstdlib>
+#include <type_traits>
 
 #include "metro_common.h"
 
@@ -38,10 +39,13 @@ constexpr int WIN_ROW_BYTES = WIN_C * 8;      // 320
 constexpr int WIN_CHUNKS = WIN_R * WIN_C / 2; // 780 16-byte chunks
 constexpr int WIN_INSTR = (WIN_CHUNKS + 63) / 64;     // 13 DMA wave-instructions
 constexpr int WIN_BYTES = WIN_INSTR * 1024;
-constexpr int CONV_ROW = 64 * 2 + 16;         // padded rows of the [conv pixel][cout] tile
+constexpr int CONV_ROW = 64 * 2 + 8;          // rows of the [conv pixel][cout] tile: 34 banks apart, so the 8-byte
+                                              // epilogue writes of 16 consecutive pixels cover the 32 banks once
 constexpr int CONV_BYTES = CPIX * CONV_ROW;
-constexpr int WIN_OFF = 0;                    // 2 buffers
-constexpr int CONV_OFF = WIN_OFF + 2 * WIN_BYTES;
+constexpr int NBUF = 3;                       // windows in flight: the current one + 2 ahead (one ahead left the
+                                              // DMA latency exposed: 6 us per patch where the arithmetic needs 1.5)
+constexpr int WIN_OFF = 0;
+constexpr int CONV_OFF = WIN_OFF + NBUF * WIN_BYTES;
 constexpr int BIAS_OFF = CONV_OFF + ((CONV_BYTES + 15) / 16) * 16;
 constexpr int LDS_BYTES = BIAS_OFF + 256;
 constexpr int KK = 14;                        // 7 tap rows x 2 k-steps of 16
@@ -67,6 +71,20 @@ __device__ __forceinline__ void sp_dma16(const void* gsrc, unsigned lds_addr) {
 template <int N>
 __device__ __forceinline__ void sp_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wave-uniform n in [0, 8]
+__device__ __forceinline__ void sp_wait_vm_dyn(int n) {
+    switch (n) {
+        case 0: sp_wait_vm<0>(); break;
+        case 1: sp_wait_vm<1>(); break;
+        case 2: sp_wait_vm<2>(); break;
+        case 3: sp_wait_vm<3>(); break;
+        case 4: sp_wait_vm<4>(); break;
+        case 5: sp_wait_vm<5>(); break;
+        case 6: sp_wait_vm<6>(); break;
+        case 7: sp_wait_vm<7>(); break;
+        default: sp_wait_vm<8>(); break;
+    }
 }
 __device__ __forceinline__ void sp_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -99,6 +117,9 @@ __global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a
             wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(i * 32 + frag_row) * 224 + kk * 16 + frag_half * 8);
     float* bias_l = reinterpret_cast<float*>(smem + BIAS_OFF);
     if (tid < 64) bias_l[tid] = a.bias[tid];
+#if defined(METRO_DBG_SP_SKIP_CONV) || defined(METRO_DBG_SP_SKIP_CONVWRITE)
+    for (int i = tid; i < CONV_BYTES / 16; i += NT) reinterpret_cast<uint4*>(smem + CONV_OFF)[i] = make_uint4(0, 0, 0, 0);
+#endif
 
     // window chunk c = q*64 + lane (q = wave + 4*i): window row c / 20, pixel pair c % 20
     auto issue_window = [&](int patch, int buf) {
@@ -114,54 +135,94 @@ __global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a
                 const int wr = c / (WIN_C / 2), wc = (c - wr * (WIN_C / 2)) * 2;
                 const int y = r0 + wr, x = c0 + wc;
                 const bool ok = c < WIN_CHUNKS && (unsigned)y < (unsigned)hp && (unsigned)x < (unsigned)wp;
+#ifdef METRO_DBG_SP_LINEAR_WINDOW   // timing experiment: same bytes, contiguous source
+                sp_dma16(ok ? a.img + ((size_t)(patch % (a.n * 8 * 8)) * WIN_BYTES / 2 + c * 8) : zero,
+#else
                 sp_dma16(ok ? base + ((size_t)y * wp + x) * 4 : zero,
+#endif
                          __builtin_amdgcn_readfirstlane(smem_base + WIN_OFF + buf * WIN_BYTES + q * 1024));
             }
         }
     };
 
+    // Window k is requested at the top of iteration k-2 (windows 0 and 1 up front).  VMEM operations of this
+    // wave younger than window `it` when iteration `it` starts: the 2 pooled stores of each iteration since the
+    // request, and the DMA instructions of window it+1 (nw per wave) if that window exists.
+    const int nw = (WIN_INSTR - wave + NW - 1) / NW;
     issue_window(p, 0);
+    if (p + G < a.n_patches) issue_window(p + G, 1);
+    int buf = 0;
     for (int it = 0;; ++it, p += G) {
-        const int buf = it & 1;
-        // the window has landed (the only younger VMEM operations are the previous patch's 2 pooled stores)
-        if (it == 0) sp_wait_vm<0>();
-        else sp_wait_vm<2>();
+        {
+            const int next_dma = p + G < a.n_patches ? nw : 0;
+            sp_wait_vm_dyn((it == 0 ? 0 : it == 1 ? 2 : 4) + next_dma);
+        }
         sp_barrier();
-        if (p + G < a.n_patches) issue_window(p + G, buf ^ 1);
+        if (p + 2 * G < a.n_patches) issue_window(p + 2 * G, buf + 2 >= NBUF ? buf + 2 - NBUF : buf + 2);
 
         const int img = p / (ppr * ppr);
         const int rem = p - img * ppr * ppr;
         const int py0 = PP * (rem / ppr), px0 = PP * (rem % ppr);
         const char* wl = smem + WIN_OFF + buf * WIN_BYTES;
         char* cl = smem + CONV_OFF;
-        // ---- conv: pixel tiles mt = wave, wave+4, wave+8 -----------------------------------------
-#pragma unroll 1
-        for (int mt = wave; mt < MT; mt += NW) {
-            const int m = mt * 32 + frag_row;
+        // ---- conv: pixel tiles mt = wave, wave+4, wave+8.  The epilogue of a tile (bias, fp16, LDS) is issued in
+        // the MFMA shadow of the NEXT tile (two accumulator sets); run back to back it cost 16 of 64 us.
+        auto tile_base = [&](int mt, int& m) -> const char* {
+            m = mt * 32 + frag_row;
             const int mc = m < CPIX ? m : CPIX - 1;
             const int cyl = mc / CP, cxl = mc - cyl * CP;
-            const char* bp = wl + (2 * cyl) * WIN_ROW_BYTES + (2 * cxl) * 8 + frag_half * 16;
-            floatx16 acc[2];
+            return wl + (2 * cyl) * WIN_ROW_BYTES + (2 * cxl) * 8 + frag_half * 16;
+        };
+        auto epi_part = [&](const floatx16 (&acc)[2], int m, int c) {      // c in [0, 8): (cout tile, quad)
+            const int i = c >> 2, q = c & 3;
+            const int co = i * 32 + 8 * q + 4 * frag_half;
+            const floatx4 bv = *reinterpret_cast<const floatx4*>(bias_l + co);
+            half4_t hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (half_t)(acc[i][4 * q + e] + bv[e]);
+#ifdef METRO_DBG_SP_SKIP_CONVWRITE
+            if (m < CPIX && a.n < 0)
+#else
+            if (m < CPIX)
+#endif
+                *reinterpret_cast<half4_t*>(cl + m * CONV_ROW + co * 2) = hv;
+        };
+        auto conv_tile = [&](int mt, floatx16 (&acc)[2], int& m, auto with_prev, const floatx16 (&pacc)[2], int pm) {
+            const char* bp = tile_base(mt, m);
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 const half8_t bf = *reinterpret_cast<const half8_t*>(bp + (kk >> 1) * WIN_ROW_BYTES + (kk & 1) * 32);
+#ifdef METRO_DBG_SP_SKIP_MFMA      // timing experiments only (tools/build_dbg_variants.sh)
+                acc[0][0] += (float)bf[0] * (float)wf[0][kk][0];
+                acc[1][0] += (float)bf[1] * (float)wf[1][kk][0];
+#else
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][kk], bf, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][kk], bf, acc[1], 0, 0, 0);
+#endif
+                if constexpr (decltype(with_prev)::value) {
+                    if (kk >= 2 && kk < 10) epi_part(pacc, pm, kk - 2);
+                }
             }
-            if (m < CPIX) {
+        };
+#ifdef METRO_DBG_SP_SKIP_CONV
+        if (a.n < 0)
+#endif
+        {
+            using Yes = std::integral_constant<bool, true>;
+            using No = std::integral_constant<bool, false>;
+            floatx16 accA[2], accB[2];
+            int mA, mB;
+            conv_tile(wave, accA, mA, No{}, accA, 0);
+            conv_tile(wave + NW, accB, mB, Yes{}, accA, mA);
+            if (wave + 2 * NW < MT) {
+                conv_tile(wave + 2 * NW, accA, mA, Yes{}, accB, mB);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int c = 0; c < 8; ++c) epi_part(accA, mA, c);
+            } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int co = i * 32 + 8 * q + 4 * frag_half;
-                        const floatx4 bv = *reinterpret_cast<const floatx4*>(bias_l + co);
-                        half4_t hv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hv[e] = (half_t)(acc[i][4 * q + e] + bv[e]);
-                        *reinterpret_cast<half4_t*>(cl + m * CONV_ROW + co * 2) = hv;
-                    }
+                for (int c = 0; c < 8; ++c) epi_part(accB, mB, c);
             }
         }
         sp_barrier();
@@ -171,24 +232,32 @@ __global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a
             const int item = tid + r * NT;
             const int c8 = item & 7, pp = item >> 3;
             const int ppy = pp >> 3, ppx = pp & 7;
+            // out-of-image conv positions contribute 0 (mask, no branches: all 9 reads are issued back to back)
             half8_t best = {};
-            bool first = true;
+#ifdef METRO_DBG_SP_SKIP_POOL
+            if (a.n < 0)
+#endif
+            {
+                uint4 v[9];                   // rows are 8-byte aligned: two 8-byte reads per window element
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int cy = 2 * (py0 + ppy) - 1 + dy;
+                for (int d = 0; d < 9; ++d) {
+                    const uint2* src = reinterpret_cast<const uint2*>(cl + ((2 * ppy + d / 3) * CP + 2 * ppx + d % 3) * CONV_ROW + c8 * 16);
+                    const uint2 lo = src[0], hi = src[1];
+                    v[d] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int cx = 2 * (px0 + ppx) - 1 + dx;
-                    half8_t v = *reinterpret_cast<const half8_t*>(cl + ((2 * ppy + dy) * CP + 2 * ppx + dx) * CONV_ROW + c8 * 16);
-                    const half8_t z = {};
-                    if (!((unsigned)cy < (unsigned)cs && (unsigned)cx < (unsigned)cs)) v = z;
-                    best = first ? v : __builtin_elementwise_max(best, v);
-                    first = false;
+                for (int d = 0; d < 9; ++d) {
+                    const int cy = 2 * (py0 + ppy) - 1 + d / 3, cx = 2 * (px0 + ppx) - 1 + d % 3;
+                    const unsigned keep = ((unsigned)cy < (unsigned)cs && (unsigned)cx < (unsigned)cs) ? 0xffffffffu : 0u;
+                    v[d].x &= keep; v[d].y &= keep; v[d].z &= keep; v[d].w &= keep;
+                    const half8_t h = *reinterpret_cast<const half8_t*>(&v[d]);
+                    best = d == 0 ? h : __builtin_elementwise_max(best, h);
                 }
             }
             *reinterpret_cast<half8_t*>(a.out + (((size_t)img * ps + py0 + ppy) * ps + px0 + ppx) * 64 + c8 * 8) = best;
         }
         if (p + G >= a.n_patches) break;
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
     }
 }
 
@@ -224,6 +293,7 @@ int launch_stem_pool_f16(const void* prepped, const void* w, const float* bias, 
         METRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, stem_pool_f16_kernel, sp::NT, sp::LDS_BYTES));
         if (occ < 1) occ = 1;
         grid_cap = cus * occ;
+        if (sp_env_int("METRO_DEBUG", 0)) fprintf(stderr, "stem_pool_f16: %d CUs x %d blocks\n", cus, occ);
     }
     const int grid = a.n_patches < grid_cap ? a.n_patches : grid_cap;
     hipLaunchKernelGGL(stem_pool_f16_kernel, dim3(grid), dim3(sp::NT), sp::LDS_BYTES, stream, a);

@@ -1,17 +1,21 @@
 #!/bin/bash
-# Timing-experiment builds of the library with parts of the LDS-DMA conv kernel compiled out
-# (results are garbage; use with METRO_HIP_LIB=metro_pose3d_amd/dbg/libmetro_<variant>.so bench.py --layer-report).
+# Timing-experiment builds of the library with parts of one kernel compiled out (results are garbage):
+#   tools/build_dbg_variants.sh <source.hip> MACRO [MACRO...]   ->  metro_pose3d_amd/dbg/libmetro_<MACRO>.so
+# use with METRO_HIP_LIB=$PWD/metro_pose3d_amd/dbg/libmetro_<MACRO>.so python bench.py --layer-report ...
 set -e
-cd "$(dirname "$0")/../metro_pose3d_amd"
-python -m metro_pose3d_amd.build >/dev/null 2>&1 || (cd .. && python -m metro_pose3d_amd.build >/dev/null)
+cd "$(dirname "$0")/.."
+python -m metro_pose3d_amd.build >/dev/null
+cd metro_pose3d_amd
+src=$1; shift
+stem=$(basename "$src" .hip)
 mkdir -p dbg
-for v in SKIP_STORE SKIP_LOAD SKIP_MFMA; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Wno-unused-function -DMETRO_DBG_$v -I../include \
-      -c csrc/conv_igemm_f16_dma.hip -o dbg/dma_$v.o &
+for v in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Wno-unused-function $(echo $v | tr "+" "\n" | sed "s/^/-DMETRO_DBG_/" | tr "\n" " ") -I../include \
+      -c csrc/$stem.hip -o dbg/${stem}_$v.o &
 done
 wait
-for v in SKIP_STORE SKIP_LOAD SKIP_MFMA; do
-  objs=$(ls build/*.o | grep -v conv_igemm_f16_dma.o)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o dbg/libmetro_$v.so $objs dbg/dma_$v.o
+for v in "$@"; do
+  objs=$(ls build/*.o | grep -v "/$stem.o")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o dbg/libmetro_$v.so $objs dbg/${stem}_$v.o
 done
-ls -la dbg/*.so
+ls dbg/*.so
