@@ -217,7 +217,7 @@ def main():
             traffic_note = (f'HBM bytes per forward summed over the {t["conv_launches"]} conv launches, '
                             f'(2*FETCH_SIZE + WRITE_SIZE)*1024 from {os.path.basename(files[-1])} '
                             f'(rocprofv3 --pmc, separate passes; avg per launch {t["conv_hbm_bytes_per_launch_avg"]:.3e} B; '
-                            f'one-round-trip-per-layer minimum {t["algorithmic_min_bytes_per_forward_fp16_every_layer_roundtrip"]:.3e} B)')
+                            f'see DESIGN.md section 4 for the algorithmic minimum)')
     if rank == 0:
         total_crops = b * world * args.steps
         ms_per_step = elapsed * 1e3 / args.steps
@@ -237,7 +237,7 @@ def main():
                        'gflop_per_crop': round(eng.flops_per_image / 1e9, 3)},
             'gpu_ms_per_step_events': round(gpu_ms / args.steps, 4),
             'whole_path_tflops': round(eng.flops_per_image * value / world / 1e12, 2),
-            'roofline': {'bound': 'mfma', 'kernel': f'conv kernels: conv_igemm_f16_dma + conv3x3_f16_slab ({n_conv} launches per forward)',
+            'roofline': {'bound': 'mfma', 'kernel': f'conv kernels: conv_igemm_f16_dma, conv3x3_f16_slab, conv_pw64 (weight-stationary), stem_pool_f16 ({n_conv} launches per forward)',
                          'achieved': round(achieved_tflops, 2), 'peak': PEAK_F16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved_tflops / PEAK_F16_DENSE_TFLOPS, 4), 'traffic': traffic,
                          'traffic_note': traffic_note,

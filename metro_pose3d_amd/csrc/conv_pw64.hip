@@ -117,11 +117,20 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;           // wave tile: couts wm*32*NI.., pixels wn*32..+32
     const int frag_row = lane & 31, frag_half = lane >> 5;
-    // 256-channel halves of wider outputs go to different blocks (the weights are register-resident)
+    // 256-channel slabs of wider outputs go to different blocks (the weights are register-resident).  Blocks are
+    // dealt round-robin to the 8 XCDs (one L2 each): the `halves` blocks that share an input tile are placed on the
+    // SAME XCD (PMC: with consecutive block ids block4's conv3 fetched its input 8 times, 203 MB instead of 84 MB).
     const int halves = a.c_out >> 8;
-    const int half = blockIdx.x % halves;
-    const int G = gridDim.x / halves;
-    int t = blockIdx.x / halves;
+    const int G = gridDim.x / halves;                       // tile streams
+    int half, t;
+    if ((gridDim.x & 7) == 0 && ((gridDim.x >> 3) % halves) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        half = j % halves;
+        t = xcd * ((gridDim.x >> 3) / halves) + j / halves;
+    } else {
+        half = blockIdx.x % halves;
+        t = blockIdx.x / halves;
+    }
     if (t >= a.n_tiles) return;
     a.w += (size_t)half * 256 * K;
     a.bias += half * 256;
