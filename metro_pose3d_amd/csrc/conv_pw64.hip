@@ -48,6 +48,9 @@ struct Pw64Args {
     half_t* out2;              // [m_total][64]
     int m_total, n_tiles;
     int c_out;                 // 256 * (number of 256-channel halves); block b serves half b % halves
+    // sub-sampled shortcut (units with stride 2, reference resnet_v2.py:113-118: max_pool2d 1x1 stride 2 of the
+    // unit input): output pixel (ho, wo) adds input pixel (res_off + 2*ho, res_off + 2*wo) of a res_h x res_w map
+    int res_stride, res_off, res_h, res_w, h_out, w_out;
 };
 
 namespace pw {
@@ -98,7 +101,7 @@ __device__ __forceinline__ void pw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int K, int WM, bool PRO, bool RES, int MODE2>
+template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false>
 __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     using namespace pw;
     using L = Lay<K, WM>;
@@ -199,7 +202,15 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
 #pragma unroll
             for (int it = 0; it < RI; ++it) {
                 const int c = it * NT + tid;
-                const half_t* rs = (m0 + (c >> 5) < a.m_total) ? a.residual + (size_t)(m0 + (c >> 5)) * ldo + (c & 31) * 8 : zero;
+                const int m = m0 + (c >> 5);
+                size_t rrow = m;
+                if constexpr (RSUB) {
+                    const int hw = a.h_out * a.w_out;
+                    const int img = m / hw, rem = m - img * hw;
+                    const int ho = rem / a.w_out, wo = rem - ho * a.w_out;
+                    rrow = ((size_t)img * a.res_h + a.res_off + a.res_stride * ho) * a.res_w + a.res_off + a.res_stride * wo;
+                }
+                const half_t* rs = m < a.m_total ? a.residual + rrow * ldo + (c & 31) * 8 : zero;
                 pw_dma16(rs, __builtin_amdgcn_readfirstlane(smem_base + RES_OFF + buf * RES_BYTES + it * 8192 + wave * 1024));
             }
         }
@@ -350,7 +361,11 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
     if (!(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_top == 0 && d.pad_left == 0 && d.in_pix_stride == d.c_in &&
           d.h_in == d.h_out && d.w_in == d.w_out && d.relu == 0 && d.out_dtype == METRO_F16 && d.in_dtype == METRO_F16))
         return false;
-    if (d.has_residual && !(d.res_stride == 1 && d.res_offset == 0 && d.res_h == d.h_out && d.res_w == d.w_out)) return false;
+    const bool res_plain = d.res_stride == 1 && d.res_offset == 0 && d.res_h == d.h_out && d.res_w == d.w_out;
+    // sub-sampled shortcut of the stride-2 units: every addressed shortcut pixel must exist
+    const bool res_sub = d.res_stride == 2 && d.res_offset >= 0 && d.res_offset + 2 * (d.h_out - 1) < d.res_h &&
+                         d.res_offset + 2 * (d.w_out - 1) < d.res_w;
+    if (d.has_residual && !res_plain && !(mode == 0 && res_sub && d.c_in <= 128)) return false;
     // built combinations: prologue without shortcut (projection shortcut, pair) / shortcut without prologue (conv3)
     if (mode == 1) return d.c_in == 64 && d.c_out == 320 && d.has_prologue && !d.has_residual;
     if (mode == 2) return d.c_in == 64 && d.c_out == 256 && !d.has_prologue && d.has_residual;
@@ -361,9 +376,9 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
            !d.has_prologue && d.has_residual;
 }
 
-template <int K, int WM, bool PRO, bool RES, int MODE2>
+template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false>
 static int launch_pw(Pw64Args a, hipStream_t stream) {
-    auto kern = conv_pw64_kernel<K, WM, PRO, RES, MODE2>;
+    auto kern = conv_pw64_kernel<K, WM, PRO, RES, MODE2, RSUB>;
     constexpr int lds = pw::lds_bytes<K, WM, RES, MODE2>();
     a.n_tiles = (a.m_total + pw::Lay<K, WM>::TN - 1) / pw::Lay<K, WM>::TN;
     static int grid_cap = 0;
@@ -407,6 +422,9 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
     a.m_total = d.n * d.h_out * d.w_out;
     a.n_tiles = 0;
     a.c_out = mode == 1 ? 256 : d.c_out;
+    a.res_stride = d.res_stride; a.res_off = d.res_offset; a.res_h = d.res_h; a.res_w = d.res_w;
+    a.h_out = d.h_out; a.w_out = d.w_out;
+    const bool rsub = d.has_residual && d.res_stride == 2;
     if (mode == 1) {
         a.w2 = a.w + 256 * 64; a.bias2 = bias + 256; a.out2 = static_cast<half_t*>(split->out2);
         return launch_pw<64, 4, true, false, 1>(a, stream);
@@ -419,9 +437,9 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
     }
     if (d.c_in == 512) return launch_pw<512, 8, false, true, 0>(a, stream);
     if (d.c_in == 256) return launch_pw<256, 8, false, true, 0>(a, stream);
-    if (d.c_in == 128) return launch_pw<128, 4, false, true, 0>(a, stream);
+    if (d.c_in == 128) return rsub ? launch_pw<128, 4, false, true, 0, true>(a, stream) : launch_pw<128, 4, false, true, 0>(a, stream);
     if (d.has_prologue) return launch_pw<64, 4, true, false, 0>(a, stream);
-    return launch_pw<64, 4, false, true, 0>(a, stream);
+    return rsub ? launch_pw<64, 4, false, true, 0, true>(a, stream) : launch_pw<64, 4, false, true, 0>(a, stream);
 }
 
 }  // namespace metro

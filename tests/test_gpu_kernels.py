@@ -87,12 +87,15 @@ def test_conv_f16(lib, cuda, case, variant):
     assert np.abs(got - ref).max() <= tol, (np.abs(got - ref).max(), scale)
 
 
+@pytest.mark.parametrize('shape', [(2, 8, 64, 128), (5, 16, 64, 256), (3, 11, 64, 256), (5, 16, 128, 512)],
+                         ids=['ring', 'pw64', 'pw64_ragged', 'pw128'])
 @pytest.mark.parametrize('res_stride,res_offset', [(2, 0), (2, 1)])
-def test_conv_f16_strided_residual(lib, cuda, res_stride, res_offset):
+def test_conv_f16_strided_residual(lib, cuda, res_stride, res_offset, shape):
     """identity shortcut of a strided unit: even pixels (non-centered) or odd pixels
-    (centered, x[1:,1:][::2,::2]) -- reference resnet_v2.py:113-121, resnet_utils.py:76-79 (KA8)."""
+    (centered, x[1:,1:][::2,::2]) -- reference resnet_v2.py:113-121, resnet_utils.py:76-79 (KA8).
+    64->256 and 128->512 run in the persistent kernel (sub-sampled shortcut rows gathered by its LDS-DMA)."""
     rng = np.random.default_rng(5 + res_offset)
-    n, h, c_in, c_out = 2, 8, 64, 128
+    n, h, c_in, c_out = shape
     x, w, b = _mk(rng, n, h, c_in, c_out, 1)
     res = rng.standard_normal((n, 2 * h, 2 * h, c_out)).astype(np.float16)
     d = H.conv_desc(n, h, c_in, h, c_out, 1, residual=True, res_h=2 * h, res_stride=res_stride,
