@@ -28,7 +28,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page_sp[4];   // zero-initialised
 
 namespace sp {
-constexpr int NT = 256, NW = 4;
+constexpr int MG = 4;                         // wave groups over the pixel tiles (tiles mg, mg+4, mg+8)
 constexpr int PP = 8;                         // pooled patch side
 constexpr int CP = 2 * PP + 1;                // conv pixels per patch side (17)
 constexpr int CPIX = CP * CP;                 // 289
@@ -90,8 +90,13 @@ __device__ __forceinline__ void sp_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a) {
+// NSPLIT = 1: 4 waves, each holds both 32-cout weight tiles (112 VGPRs) and reuses every pixel fragment twice;
+// NSPLIT = 2: 8 waves, a wave holds one cout tile (56 VGPRs): twice the waves per CU to overlap the phases
+template <int NSPLIT>
+__global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f16_kernel(StemPoolArgs a) {
     using namespace sp;
+    constexpr int NW = MG * NSPLIT, NT = 64 * NW, CT = 2 / NSPLIT;
+    constexpr int PS = 512 / NT;                  // pooled stores per wave per patch
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void_t;
     const unsigned smem_base = (unsigned)(size_t)(lds_void_t*)smem;
@@ -109,12 +114,14 @@ __global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a
     const int cs = a.side / 2;                           // conv side
 
     // ---- launch-resident weights: both 32-cout tiles, 14 k-steps ------------------------------
-    half8_t wf[2][KK];
+    const int ct0 = NSPLIT == 2 ? (wave & 1) : 0;          // first cout tile of this wave
+    const int mg = NSPLIT == 2 ? (wave >> 1) : wave;       // pixel-tile group
+    half8_t wf[CT][KK];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < CT; ++i)
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
-            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(i * 32 + frag_row) * 224 + kk * 16 + frag_half * 8);
+            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)((ct0 + i) * 32 + frag_row) * 224 + kk * 16 + frag_half * 8);
     float* bias_l = reinterpret_cast<float*>(smem + BIAS_OFF);
     if (tid < 64) bias_l[tid] = a.bias[tid];
 #if defined(METRO_DBG_SP_SKIP_CONV) || defined(METRO_DBG_SP_SKIP_CONVWRITE)
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a
     };
 
     // Window k is requested at the top of iteration k-2 (windows 0 and 1 up front).  VMEM operations of this
-    // wave younger than window `it` when iteration `it` starts: the 2 pooled stores of each iteration since the
+    // wave younger than window `it` when iteration `it` starts: the PS pooled stores of each iteration since the
     // request, and the DMA instructions of window it+1 (nw per wave) if that window exists.
     const int nw = (WIN_INSTR - wave + NW - 1) / NW;
     issue_window(p, 0);
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a
     for (int it = 0;; ++it, p += G) {
         {
             const int next_dma = p + G < a.n_patches ? nw : 0;
-            sp_wait_vm_dyn((it == 0 ? 0 : it == 1 ? 2 : 4) + next_dma);
+            sp_wait_vm_dyn((it == 0 ? 0 : it == 1 ? PS : 2 * PS) + next_dma);
         }
         sp_barrier();
         if (p + 2 * G < a.n_patches) issue_window(p + 2 * G, buf + 2 >= NBUF ? buf + 2 - NBUF : buf + 2);
@@ -173,9 +180,9 @@ __global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a
             const int cyl = mc / CP, cxl = mc - cyl * CP;
             return wl + (2 * cyl) * WIN_ROW_BYTES + (2 * cxl) * 8 + frag_half * 16;
         };
-        auto epi_part = [&](const floatx16 (&acc)[2], int m, int c) {      // c in [0, 8): (cout tile, quad)
+        auto epi_part = [&](const floatx16 (&acc)[CT], int m, int c) {     // c in [0, 4*CT): (cout tile, quad)
             const int i = c >> 2, q = c & 3;
-            const int co = i * 32 + 8 * q + 4 * frag_half;
+            const int co = (ct0 + i) * 32 + 8 * q + 4 * frag_half;
             const floatx4 bv = *reinterpret_cast<const floatx4*>(bias_l + co);
             half4_t hv;
 #pragma unroll
@@ -187,22 +194,24 @@ __global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a
 #endif
                 *reinterpret_cast<half4_t*>(cl + m * CONV_ROW + co * 2) = hv;
         };
-        auto conv_tile = [&](int mt, floatx16 (&acc)[2], int& m, auto with_prev, const floatx16 (&pacc)[2], int pm) {
+        auto conv_tile = [&](int mt, floatx16 (&acc)[CT], int& m, auto with_prev, const floatx16 (&pacc)[CT], int pm) {
             const char* bp = tile_base(mt, m);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int i = 0; i < CT; ++i) acc[i][e] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 const half8_t bf = *reinterpret_cast<const half8_t*>(bp + (kk >> 1) * WIN_ROW_BYTES + (kk & 1) * 32);
 #ifdef METRO_DBG_SP_SKIP_MFMA      // timing experiments only (tools/build_dbg_variants.sh)
-                acc[0][0] += (float)bf[0] * (float)wf[0][kk][0];
-                acc[1][0] += (float)bf[1] * (float)wf[1][kk][0];
+#pragma unroll
+                for (int i = 0; i < CT; ++i) acc[i][0] += (float)bf[i] * (float)wf[i][kk][0];
 #else
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][kk], bf, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][kk], bf, acc[1], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < CT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][kk], bf, acc[i], 0, 0, 0);
 #endif
                 if constexpr (decltype(with_prev)::value) {
-                    if (kk >= 2 && kk < 10) epi_part(pacc, pm, kk - 2);
+                    if (kk >= 2 && kk < 2 + 4 * CT) epi_part(pacc, pm, kk - 2);
                 }
             }
         };
@@ -212,23 +221,35 @@ __global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a
         {
             using Yes = std::integral_constant<bool, true>;
             using No = std::integral_constant<bool, false>;
-            floatx16 accA[2], accB[2];
-            int mA, mB;
-            conv_tile(wave, accA, mA, No{}, accA, 0);
-            conv_tile(wave + NW, accB, mB, Yes{}, accA, mA);
-            if (wave + 2 * NW < MT) {
-                conv_tile(wave + 2 * NW, accA, mA, Yes{}, accB, mB);
+            floatx16 accA[CT];
+            int mA;
+            if constexpr (NSPLIT == 2) {
+                // one accumulator set (128-VGPR budget of 4 waves per SIMD): tiles one after the other
+#pragma unroll 1
+                for (int mt = mg; mt < MT; mt += MG) {
+                    conv_tile(mt, accA, mA, No{}, accA, 0);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) epi_part(accA, mA, c);
+                    for (int c = 0; c < 4 * CT; ++c) epi_part(accA, mA, c);
+                }
+            } else {
+            floatx16 accB[CT];
+            int mB;
+            conv_tile(mg, accA, mA, No{}, accA, 0);
+            conv_tile(mg + MG, accB, mB, Yes{}, accA, mA);
+            if (mg + 2 * MG < MT) {
+                conv_tile(mg + 2 * MG, accA, mA, Yes{}, accB, mB);
+#pragma unroll
+                for (int c = 0; c < 4 * CT; ++c) epi_part(accA, mA, c);
             } else {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) epi_part(accB, mB, c);
+                for (int c = 0; c < 4 * CT; ++c) epi_part(accB, mB, c);
+            }
             }
         }
         sp_barrier();
         // ---- pool: (pooled pixel, 8-channel chunk) items, zero where the conv position is outside -------
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < PS; ++r) {
             const int item = tid + r * NT;
             const int c8 = item & 7, pp = item >> 3;
             const int ppy = pp >> 3, ppx = pp & 7;
@@ -238,20 +259,23 @@ __global__ __launch_bounds__(sp::NT, 2) void stem_pool_f16_kernel(StemPoolArgs a
             if (a.n < 0)
 #endif
             {
-                uint4 v[9];                   // rows are 8-byte aligned: two 8-byte reads per window element
 #pragma unroll
-                for (int d = 0; d < 9; ++d) {
-                    const uint2* src = reinterpret_cast<const uint2*>(cl + ((2 * ppy + d / 3) * CP + 2 * ppx + d % 3) * CONV_ROW + c8 * 16);
-                    const uint2 lo = src[0], hi = src[1];
-                    v[d] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
+                for (int dy = 0; dy < 3; ++dy) {           // one window row at a time (3 reads in flight: registers)
+                    uint4 v[3];                            // rows are 8-byte aligned: two 8-byte reads per element
 #pragma unroll
-                for (int d = 0; d < 9; ++d) {
-                    const int cy = 2 * (py0 + ppy) - 1 + d / 3, cx = 2 * (px0 + ppx) - 1 + d % 3;
-                    const unsigned keep = ((unsigned)cy < (unsigned)cs && (unsigned)cx < (unsigned)cs) ? 0xffffffffu : 0u;
-                    v[d].x &= keep; v[d].y &= keep; v[d].z &= keep; v[d].w &= keep;
-                    const half8_t h = *reinterpret_cast<const half8_t*>(&v[d]);
-                    best = d == 0 ? h : __builtin_elementwise_max(best, h);
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const uint2* src = reinterpret_cast<const uint2*>(cl + ((2 * ppy + dy) * CP + 2 * ppx + dx) * CONV_ROW + c8 * 16);
+                        const uint2 lo = src[0], hi = src[1];
+                        v[dx] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    }
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int cy = 2 * (py0 + ppy) - 1 + dy, cx = 2 * (px0 + ppx) - 1 + dx;
+                        const unsigned keep = ((unsigned)cy < (unsigned)cs && (unsigned)cx < (unsigned)cs) ? 0xffffffffu : 0u;
+                        v[dx].x &= keep; v[dx].y &= keep; v[dx].z &= keep; v[dx].w &= keep;
+                        const half8_t h = *reinterpret_cast<const half8_t*>(&v[dx]);
+                        best = (dy == 0 && dx == 0) ? h : __builtin_elementwise_max(best, h);
+                    }
                 }
             }
             *reinterpret_cast<half8_t*>(a.out + (((size_t)img * ps + py0 + ppy) * ps + px0 + ppx) * 64 + c8 * 8) = best;
@@ -271,6 +295,9 @@ bool stem_pool_f16_supported(int side, int base_width) {
     return enabled && base_width == 64 && side % 32 == 0 && side >= 32;
 }
 
+template <int NSPLIT>
+static int launch_sp(const StemPoolArgs& a, hipStream_t stream);
+
 int launch_stem_pool_f16(const void* prepped, const void* w, const float* bias, void* out, int n, int side,
                          hipStream_t stream) {
     if (!stem_pool_f16_supported(side, 64)) { set_error("stem_pool_f16: unsupported shape (side %d)", side); return METRO_ERR_INVALID_ARG; }
@@ -282,21 +309,30 @@ int launch_stem_pool_f16(const void* prepped, const void* w, const float* bias, 
     a.n = n; a.side = side;
     const int ppr = side / 4 / sp::PP;
     a.n_patches = n * ppr * ppr;
+    static const int split = sp_env_int("METRO_STEM_SPLIT", 2);
+    if (split == 2) return launch_sp<2>(a, stream);
+    return launch_sp<1>(a, stream);
+}
+
+template <int NSPLIT>
+static int launch_sp(const StemPoolArgs& a, hipStream_t stream) {
+    auto kern = stem_pool_f16_kernel<NSPLIT>;
+    constexpr int NT = 64 * sp::MG * NSPLIT;
     static int grid_cap = 0;
     if (grid_cap == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_f16_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, sp::LDS_BYTES);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute(stem_pool): %s", hipGetErrorString(e)); return METRO_ERR_HIP; }
         int dev = 0, cus = 0, occ = 0;
         METRO_HIP_CHECK(hipGetDevice(&dev));
         METRO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        METRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, stem_pool_f16_kernel, sp::NT, sp::LDS_BYTES));
+        METRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, NT, sp::LDS_BYTES));
         if (occ < 1) occ = 1;
         grid_cap = cus * occ;
         if (sp_env_int("METRO_DEBUG", 0)) fprintf(stderr, "stem_pool_f16: %d CUs x %d blocks\n", cus, occ);
     }
     const int grid = a.n_patches < grid_cap ? a.n_patches : grid_cap;
-    hipLaunchKernelGGL(stem_pool_f16_kernel, dim3(grid), dim3(sp::NT), sp::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), sp::LDS_BYTES, stream, a);
     return launch_status("stem_pool_f16");
 }
 
