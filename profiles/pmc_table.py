@@ -35,9 +35,7 @@ def main():
     names = []
     for li in infos:
         names.append(li.name.decode())
-        if li.kind == 3:
-            names.append('softargmax_fin')
-    per = len(names)
+    two_launch_head = None
     merged = defaultdict(dict)
     meta = {}
     for p in sorted(os.listdir(base)):
@@ -45,6 +43,11 @@ def main():
         if not os.path.isdir(d) or not glob.glob(os.path.join(d, '*_counter_collection.csv')):
             continue
         rows = load(d)
+        if two_launch_head is None:        # batch >= 32 on <= 256 pixels: soft-argmax is one launch, else partial + finalize
+            two_launch_head = any('softargmax_finalize' in r['name'] for r in rows)
+            if two_launch_head:
+                names.append('softargmax_fin')
+            per = len(names)
         rows = rows[fwd * per:(fwd + 1) * per]
         for i, r in enumerate(rows):
             merged[i].update(r['c'])
