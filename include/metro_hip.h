@@ -168,6 +168,26 @@ typedef struct MetroConvDesc {
 int  metro_conv_f16(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                     const void* d_pro_scale, const void* d_pro_shift, const void* d_residual,
                     void* d_out, void* stream);
+/* Two 1x1 convolutions of a bottleneck unit on the SAME pre-activated input in one launch: the projection
+ * shortcut (rows [0, split) of d_w / d_bias, no ReLU, -> d_out with `split` channels) and conv1 with its folded
+ * BN + ReLU (rows [split, d->c_out) -> d_out2 with d->c_out - split channels).  Replaces the two
+ * layers_lib.conv2d calls of reference src/model/resnet_v2.py:122-128.  d->has_prologue = 1, no residual. */
+int  metro_conv_f16_pair(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
+                         const void* d_pro_scale, const void* d_pro_shift, void* d_out, int32_t split,
+                         void* d_out2, void* stream);
+/* conv3 (+bias, + shortcut) of unit u and conv1 (pre-activation BN+ReLU of unit u+1, folded BN + ReLU) of
+ * unit u+1 in one launch (block1 shapes: c_in = c2 = 64, c_out = 256):
+ *   d_out  = conv(d_in) + bias + residual                          (resnet_v2.py:134-138 of unit u)
+ *   d_out2 = relu(W2 * relu(d_out * scale2 + shift2) + bias2)      (resnet_v2.py:119,127-128 of unit u+1)
+ * W2 fp16 [c2][c_out], bias2 fp32 [c2], scale2/shift2 fp16 [c_out], d_out2 fp16 [.., c2]. */
+int  metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
+                         const void* d_residual, void* d_out, const void* d_w2, const float* d_bias2,
+                         const void* d_scale2, const void* d_shift2, void* d_out2, int32_t c2, void* stream);
+/* Stem 7x7/2 convolution (+bias) and zero-padded 3x3/2 max-pool in one launch (reference resnet_v2.py:219-224,
+ * resnet_utils.py:138-185).  d_prepped = metro_prep_input_f16 output [n,side+6,side+8,4] fp16, d_w packed
+ * [64][7][8][4] fp16, d_out fp16 [n,side/4,side/4,64].  side % 32 == 0. */
+int  metro_stem_pool_f16(const void* d_prepped, const void* d_w, const float* d_bias, void* d_out, int32_t n,
+                         int32_t side, void* stream);
 /* fp32 or fp64 activations (in_dtype / out_dtype), fp64 weights/bias/prologue,
  * v_mfma_f64_16x16x4_f64 accumulate, one rounding to out_dtype. */
 int  metro_conv_f64acc(const MetroConvDesc* d, const void* d_in, const double* d_w,

@@ -74,6 +74,9 @@ SIGNATURES = {
     'metro_forward_timed': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_float)]),
     'metro_conv_f16': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f64acc': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    'metro_conv_f16_pair': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
+    'metro_conv_f16_next': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    'metro_stem_pool_f16': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     'metro_prep_input_f16': (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     'metro_warp_crop_u8': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
     'metro_eval_metrics': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P]),

@@ -712,6 +712,47 @@ int metro_conv_f16(const MetroConvDesc* d, const void* d_in, const void* d_w, co
                            static_cast<hipStream_t>(stream));
 }
 
+int metro_conv_f16_pair(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
+                        const void* d_pro_scale, const void* d_pro_shift, void* d_out, int32_t split,
+                        void* d_out2, void* stream) {
+    int st = validate_conv_desc(d);
+    if (st) return st;
+    METRO_CHECK_ARG(d->in_dtype == METRO_F16 && d->out_dtype == METRO_F16, "conv_f16_pair: fp16 tensors only");
+    METRO_CHECK_ARG(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->has_prologue && !d->has_residual && !d->relu,
+                    "conv_f16_pair: 1x1 stride-1 convolution with prologue, without residual/ReLU on the first output");
+    METRO_CHECK_ARG(d_in && d_w && d_bias && d_out && d_out2 && d_pro_scale && d_pro_shift, "conv_f16_pair: NULL tensor pointer");
+    METRO_CHECK_ARG(split > 0 && split < d->c_out && split % 256 == 0 && (d->c_out - split) % 8 == 0 && d->c_in % 64 == 0,
+                    "conv_f16_pair: split %d of c_out %d (split %% 256, rest %% 8, c_in %% 64 required)", split, d->c_out);
+    ConvSplit sp;
+    sp.split = split; sp.c_out2 = d->c_out - split; sp.relu2 = 1; sp.out2 = d_out2;
+    return launch_conv_f16_dma(*d, d_in, d_w, d_bias, d_pro_scale, d_pro_shift, nullptr, d_out,
+                               static_cast<hipStream_t>(stream), &sp);
+}
+
+int metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
+                        const void* d_residual, void* d_out, const void* d_w2, const float* d_bias2,
+                        const void* d_scale2, const void* d_shift2, void* d_out2, int32_t c2, void* stream) {
+    int st = validate_conv_desc(d);
+    if (st) return st;
+    METRO_CHECK_ARG(d_in && d_w && d_bias && d_out && d_w2 && d_bias2 && d_scale2 && d_shift2 && d_out2,
+                    "conv_f16_next: NULL tensor pointer");
+    METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f16_next: residual tensor missing");
+    METRO_CHECK_ARG(conv_f16_fuse2_supported(*d, c2) || conv_pw64_supported(*d, 2),
+                    "conv_f16_next: built for 1x1 stride-1 64 -> 256 with c2 = 64 (block1), fp16");
+    ConvFuse2 f2;
+    f2.w2 = d_w2; f2.bias2 = d_bias2; f2.scale2 = d_scale2; f2.shift2 = d_shift2; f2.out2 = d_out2; f2.c2 = c2;
+    return launch_conv_f16_dma(*d, d_in, d_w, d_bias, nullptr, nullptr, d_residual, d_out,
+                               static_cast<hipStream_t>(stream), nullptr, &f2);
+}
+
+int metro_stem_pool_f16(const void* d_prepped, const void* d_w, const float* d_bias, void* d_out, int32_t n,
+                        int32_t side, void* stream) {
+    METRO_CHECK_ARG(d_prepped && d_w && d_bias && d_out, "stem_pool_f16: NULL tensor pointer");
+    METRO_CHECK_ARG(n > 0, "stem_pool_f16: n = %d", n);
+    METRO_CHECK_ARG(stem_pool_f16_supported(side, 64), "stem_pool_f16: side %d must be a multiple of 32 (and METRO_STEM_POOL != 0)", side);
+    return launch_stem_pool_f16(d_prepped, d_w, d_bias, d_out, n, side, static_cast<hipStream_t>(stream));
+}
+
 int metro_conv_f64acc(const MetroConvDesc* d, const void* d_in, const double* d_w, const double* d_bias,
                       const double* d_pro_scale, const double* d_pro_shift, const void* d_residual,
                       void* d_out, void* stream) {

@@ -106,6 +106,106 @@ def test_conv_f16_strided_residual(lib, cuda, res_stride, res_offset, shape):
     assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()
 
 
+def _dev(a, cuda, dt):
+    return torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(cuda)
+
+
+@pytest.mark.parametrize('shape', [(3, 7, 64, 256, 64), (25, 64, 64, 256, 64), (2, 16, 256, 512, 128), (3, 9, 512, 1024, 256)],
+                         ids=['block1_ragged', 'block1_many_tiles', 'block2', 'block3_ragged'])
+def test_conv_f16_pair(lib, cuda, shape):
+    """Projection shortcut + conv1 of a unit in one launch (reference resnet_v2.py:122-128): both outputs
+    against the fp64 reference on the same fp16 operands.  64 -> 256+64 runs in the persistent kernel."""
+    n, h, c_in, c_sc, cb = shape
+    rng = np.random.default_rng(zlib.crc32(repr(shape).encode()))
+    x, w, b = _mk(rng, n, h, c_in, c_sc + cb, 1)
+    x16, w16 = x.astype(np.float16), w.astype(np.float16)
+    sc = rng.uniform(0.5, 1.5, c_in).astype(np.float16)
+    sh = (rng.standard_normal(c_in) * 0.2).astype(np.float16)
+    d = H.conv_desc(n, h, c_in, h, c_sc + cb, 1, prologue=True, in_dtype=_lib.METRO_F16)
+    out = torch.full((n, h, h, c_sc), float('nan'), dtype=torch.float16, device=cuda)
+    out2 = torch.full((n, h, h, cb), float('nan'), dtype=torch.float16, device=cuda)
+    tx, tw, tb, ts, tsh = _dev(x16, cuda, np.float16), _dev(w16, cuda, np.float16), _dev(b, cuda, np.float32), _dev(sc, cuda, np.float16), _dev(sh, cuda, np.float16)
+    check(lib.metro_conv_f16_pair(C.byref(d), H.ptr(tx), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(out), c_sc,
+                                  H.ptr(out2), None), 'metro_conv_f16_pair')
+    torch.cuda.synchronize()
+    xin = np.maximum(np.float16(x16.astype(np.float64) * sc.astype(np.float64) + sh.astype(np.float64)), 0)
+    ref = H.ref_conv_nhwc(xin.astype(np.float64), w16, b, 1, 1, 0, h).numpy()
+    got, got2 = out.cpu().double().numpy(), out2.cpu().double().numpy()
+    assert np.isfinite(got).all() and np.isfinite(got2).all()
+    tol = 2e-3 * np.abs(ref).max()
+    assert np.abs(got - ref[..., :c_sc]).max() <= tol
+    assert np.abs(got2 - np.maximum(ref[..., c_sc:], 0)).max() <= tol
+
+
+@pytest.mark.parametrize('shape', [(3, 7), (2, 8), (12, 64)], ids=['ragged', 'small', 'many_tiles'])
+def test_conv_f16_next(lib, cuda, shape):
+    """conv3 + shortcut of unit u and conv1 of unit u+1 in one launch (reference resnet_v2.py:134-138 then
+    :119,127-128): first output against the fp64 reference, second output against a restatement on the fp16
+    first output the kernel itself stored (tight)."""
+    n, h = shape
+    c_in, c_out, c2 = 64, 256, 64
+    rng = np.random.default_rng(zlib.crc32(repr(shape).encode()) + 1)
+    x, w, b = _mk(rng, n, h, c_in, c_out, 1)
+    res = rng.standard_normal((n, h, h, c_out)).astype(np.float16)
+    w2 = (rng.standard_normal((c2, c_out)) * np.sqrt(2.0 / c_out)).astype(np.float16)
+    b2 = (rng.standard_normal(c2) * 0.1).astype(np.float32)
+    sc2 = rng.uniform(0.5, 1.5, c_out).astype(np.float16)
+    sh2 = (rng.standard_normal(c_out) * 0.2).astype(np.float16)
+    d = H.conv_desc(n, h, c_in, h, c_out, 1, residual=True, res_h=h, in_dtype=_lib.METRO_F16)
+    out = torch.full((n, h, h, c_out), float('nan'), dtype=torch.float16, device=cuda)
+    out2 = torch.full((n, h, h, c2), float('nan'), dtype=torch.float16, device=cuda)
+    t = [_dev(x, cuda, np.float16), _dev(w, cuda, np.float16), _dev(b, cuda, np.float32), _dev(res, cuda, np.float16),
+         _dev(w2, cuda, np.float16), _dev(b2, cuda, np.float32), _dev(sc2, cuda, np.float16), _dev(sh2, cuda, np.float16)]
+    check(lib.metro_conv_f16_next(C.byref(d), H.ptr(t[0]), H.ptr(t[1]), H.ptr(t[2]), H.ptr(t[3]), H.ptr(out), H.ptr(t[4]),
+                                  H.ptr(t[5]), H.ptr(t[6]), H.ptr(t[7]), H.ptr(out2), c2, None), 'metro_conv_f16_next')
+    torch.cuda.synchronize()
+    ref = H.ref_conv_nhwc(x.astype(np.float16), w.astype(np.float16), b, 1, 1, 0, h, res=res).numpy()
+    got, got2 = out.cpu().double().numpy(), out2.cpu().double().numpy()
+    assert np.isfinite(got).all() and np.isfinite(got2).all()
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()
+    pre = np.maximum(np.float16(got * sc2.astype(np.float64) + sh2.astype(np.float64)), 0).astype(np.float64)
+    want2 = np.maximum(pre @ w2.astype(np.float64).T + b2.astype(np.float64), 0)
+    assert np.abs(got2 - want2).max() <= 2e-3 * np.abs(want2).max()
+
+
+@pytest.mark.parametrize('n,side', [(2, 64), (3, 96), (9, 256)])
+def test_stem_pool_f16(lib, cuda, n, side):
+    """Stem 7x7/2 + zero-padded 3x3/2 max-pool in one launch against torch fp64 on the same fp16 operands
+    (reference resnet_v2.py:219-224, resnet_utils.py:138-185); 9 x 256^2 = more patches than resident blocks."""
+    rng = np.random.default_rng(n * 1000 + side)
+    img = rng.uniform(-1, 1, (n, side, side, 3)).astype(np.float32)
+    w = (rng.standard_normal((64, 7, 7, 3)) * np.sqrt(2.0 / 147)).astype(np.float16)      # [o][kh][kw][c]
+    b = (rng.standard_normal(64) * 0.5).astype(np.float32)
+    wp = np.zeros((64, 7, 8, 4), np.float16)
+    wp[:, :, :7, :3] = w
+    timg = torch.from_numpy(img).to(cuda)
+    prepped = torch.empty((n, side + 6, side + 8, 4), dtype=torch.float16, device=cuda)
+    check(lib.metro_prep_input_f16(H.ptr(timg), n, side, H.ptr(prepped), None), 'metro_prep_input_f16')
+    out = torch.full((n, side // 4, side // 4, 64), float('nan'), dtype=torch.float16, device=cuda)
+    tw, tb = _dev(wp, cuda, np.float16), _dev(b, cuda, np.float32)      # named: a temporary would be freed before the launch
+    check(lib.metro_stem_pool_f16(H.ptr(prepped), H.ptr(tw), H.ptr(tb), H.ptr(out), n, side, None), 'metro_stem_pool_f16')
+    torch.cuda.synchronize()
+    xi = torch.from_numpy(img.astype(np.float16).astype(np.float64)).permute(0, 3, 1, 2)
+    conv = torch.nn.functional.conv2d(torch.nn.functional.pad(xi, (3, 3, 3, 3)),
+                                      torch.from_numpy(w.astype(np.float64)).permute(0, 3, 1, 2),
+                                      torch.from_numpy(b.astype(np.float64)), stride=2).half().double()
+    want = torch.nn.functional.max_pool2d(torch.nn.functional.pad(conv, (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1).numpy()
+    got = out.cpu().double().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
+    assert (got == want).mean() > 0.98
+
+
+def test_fused_entry_points_reject_unsupported_shapes(lib, cuda):
+    d = H.conv_desc(1, 8, 64, 8, 128, 1, residual=True, res_h=8, in_dtype=_lib.METRO_F16)     # c_out != 256
+    p = C.c_void_p(256)
+    assert lib.metro_conv_f16_next(C.byref(d), p, p, p, p, p, p, p, p, p, p, 64, None) == -1
+    assert b'conv_f16_next' in lib.metro_last_error()
+    d = H.conv_desc(1, 8, 64, 8, 320, 1, prologue=True, in_dtype=_lib.METRO_F16)
+    assert lib.metro_conv_f16_pair(C.byref(d), p, p, p, p, p, p, 100, p, None) == -1        # split % 256
+    assert lib.metro_stem_pool_f16(p, p, p, p, 1, 100, None) == -1                            # side % 32
+
+
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 @pytest.mark.parametrize('variant', ['plain', 'relu_residual', 'prologue'])
 @pytest.mark.parametrize('store', ['f32', 'f64'])
