@@ -188,6 +188,10 @@ int  metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d
  * [64][7][8][4] fp16, d_out fp16 [n,side/4,side/4,64].  side % 32 == 0. */
 int  metro_stem_pool_f16(const void* d_prepped, const void* d_w, const float* d_bias, void* d_out, int32_t n,
                          int32_t side, void* stream);
+/* Same, reading the fp32 NHWC crops [n,side,side,3] directly: the fp32->fp16 cast (reference
+ * src/model/architectures.py:29) and the stem's zero border happen on the way into LDS. */
+int  metro_stem_pool_f32in(const float* d_images, const void* d_w, const float* d_bias, void* d_out, int32_t n,
+                           int32_t side, void* stream);
 /* fp32 or fp64 activations (in_dtype / out_dtype), fp64 weights/bias/prologue,
  * v_mfma_f64_16x16x4_f64 accumulate, one rounding to out_dtype. */
 int  metro_conv_f64acc(const MetroConvDesc* d, const void* d_in, const double* d_w,

@@ -77,6 +77,7 @@ SIGNATURES = {
     'metro_conv_f16_pair': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
     'metro_conv_f16_next': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     'metro_stem_pool_f16': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
+    'metro_stem_pool_f32in': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     'metro_prep_input_f16': (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     'metro_warp_crop_u8': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
     'metro_eval_metrics': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P]),

@@ -110,6 +110,10 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
 bool stem_pool_f16_supported(int side, int base_width);
 int launch_stem_pool_f16(const void* prepped, const void* w, const float* bias, void* out, int n, int side,
                          hipStream_t stream);
+// same, reading the fp32 NHWC3 crops directly (prep_input_f16 fused away)
+bool stem_pool_f32in_supported(int side, int base_width);
+int launch_stem_pool_f32in(const float* images, const void* w, const float* bias, void* out, int n, int side,
+                           hipStream_t stream);
 // 3x3 stride-1 convs with tap reuse from an LDS-resident activation slab
 bool conv3x3_slab_supported(const MetroConvDesc& d);
 int launch_conv3x3_slab(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out,

@@ -279,6 +279,8 @@ int build_plan(MetroPlan* p) {
     // reference resnet_v2.py:219-224, resnet_utils.py:125-135,177-185
     const int s2 = (side + 6 - 7) / 2 + 1;   // 128
     bool fused_stem_pool = false;
+    // the fused stem+pool kernel can read the fp32 crops directly (cast + border on the way into LDS)
+    const bool raw_stem = fast && stem_pool_f32in_supported(side, bw);
     if (fast) {
         Layer L;
         memset(&L, 0, sizeof(L));
@@ -288,9 +290,11 @@ int build_plan(MetroPlan* p) {
         L.cd.h_out = side + 6; L.cd.w_out = side + 8; L.cd.c_out = 4; L.cd.out_dtype = METRO_F16;
         L.in_slot = S_IMAGES; L.out_slot = S_PREP; L.res_slot = S_NONE;
         L.p_w = L.p_bias = L.p_scale = L.p_shift = -1;
-        B.need(S_PREP, (int64_t)(side + 6) * (side + 8) * 4 * 2);
-        B.fill_info(L, "prep_input", 0.0);
-        p->layers.push_back(L);
+        if (!raw_stem) {
+            B.need(S_PREP, (int64_t)(side + 6) * (side + 8) * 4 * 2);
+            B.fill_info(L, "prep_input", 0.0);
+            p->layers.push_back(L);
+        }
 
         // stem as a pad-free 7x1-tap conv over the bordered 4-channel image: each tap = 8
         // pixels x 4 channels = 32 contiguous fp16; weights packed [c_out][7][8][4] (zeros in
@@ -312,7 +316,8 @@ int build_plan(MetroPlan* p) {
         if (stem_pool_f16_supported(side, bw)) {
             // reference resnet_v2.py:219-224: the pooled tensor is the only thing block1 reads
             fused_stem_pool = true;
-            S.stem_pool = 1;
+            S.stem_pool = raw_stem ? 2 : 1;
+            if (raw_stem) S.in_slot = S_IMAGES;
             S.out_slot = S_X0;
             const int s4f = (s2 + 2 - 3) / 2 + 1;
             B.need(S_X0, (int64_t)s4f * s4f * bw * aes);
@@ -517,7 +522,10 @@ int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_
             case LK_CONV: {
                 MetroConvDesc cd = L.cd;
                 cd.n = n;
-                if (p->fast && L.stem_pool) {
+                if (p->fast && L.stem_pool == 2) {
+                    st = launch_stem_pool_f32in(images, prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
+                                                slot_ptr(L.out_slot), n, p->spec.proc_side, stream);
+                } else if (p->fast && L.stem_pool) {
                     st = launch_stem_pool_f16(slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
                                               slot_ptr(L.out_slot), n, p->spec.proc_side, stream);
                 } else if (p->fast && L.split > 0) {
@@ -751,6 +759,14 @@ int metro_stem_pool_f16(const void* d_prepped, const void* d_w, const float* d_b
     METRO_CHECK_ARG(n > 0, "stem_pool_f16: n = %d", n);
     METRO_CHECK_ARG(stem_pool_f16_supported(side, 64), "stem_pool_f16: side %d must be a multiple of 32 (and METRO_STEM_POOL != 0)", side);
     return launch_stem_pool_f16(d_prepped, d_w, d_bias, d_out, n, side, static_cast<hipStream_t>(stream));
+}
+
+int metro_stem_pool_f32in(const float* d_images, const void* d_w, const float* d_bias, void* d_out, int32_t n,
+                          int32_t side, void* stream) {
+    METRO_CHECK_ARG(d_images && d_w && d_bias && d_out, "stem_pool_f32in: NULL tensor pointer");
+    METRO_CHECK_ARG(n > 0, "stem_pool_f32in: n = %d", n);
+    METRO_CHECK_ARG(stem_pool_f32in_supported(side, 64), "stem_pool_f32in: side %d must be a multiple of 32 (and METRO_STEM_POOL / METRO_STEM_RAW != 0)", side);
+    return launch_stem_pool_f32in(d_images, d_w, d_bias, d_out, n, side, static_cast<hipStream_t>(stream));
 }
 
 int metro_conv_f64acc(const MetroConvDesc* d, const void* d_in, const double* d_w, const double* d_bias,

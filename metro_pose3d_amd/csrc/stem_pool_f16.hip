@@ -52,6 +52,7 @@ constexpr int KK = 14;                        // 7 tap rows x 2 k-steps of 16
 }  // namespace sp
 
 struct StemPoolArgs {
+    const float* img_f32;  // RAW: [n][side][side][3] fp32, cast + bordered on the way into LDS (architectures.py:29)
     const half_t* img;     // [n][side+6][side+8][4] fp16 (prep_input_f16)
     const half_t* w;       // [64][7][8][4] fp16
     const float* bias;     // [64]
@@ -92,7 +93,10 @@ __device__ __forceinline__ void sp_barrier() {
 
 // NSPLIT = 1: 4 waves, each holds both 32-cout weight tiles (112 VGPRs) and reuses every pixel fragment twice;
 // NSPLIT = 2: 8 waves, a wave holds one cout tile (56 VGPRs): twice the waves per CU to overlap the phases
-template <int NSPLIT>
+// RAW: the fp32 NHWC3 crops are read directly (prep_input_f16 fused away): every thread fetches ~3 window pixels
+// of the NEXT patch into registers at the top of an iteration and writes them to the other window buffer as
+// zero-bordered 4-channel fp16 at the end of it (ordinary loads: the compiler places their waits).
+template <int NSPLIT, bool RAW>
 __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f16_kernel(StemPoolArgs a) {
     using namespace sp;
     constexpr int NW = MG * NSPLIT, NT = 64 * NW, CT = 2 / NSPLIT;
@@ -152,20 +156,58 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
         }
     };
 
+    // RAW: window pixel idx = k*NT + tid (row idx / 40, column idx % 40 of the bordered window)
+    constexpr int RK = (WIN_R * WIN_C + NT - 1) / NT;
+    float rawpx[RAW ? RK : 1][3];
+    auto raw_fetch = [&](int patch) {
+        const int img = patch / (ppr * ppr);
+        const int rem = patch - img * ppr * ppr;
+        const int r0 = 4 * PP * (rem / ppr) - 2 - 3, c0 = 4 * PP * (rem % ppr) - 2 - 3;   // window origin in the IMAGE
+        const float* base = a.img_f32 + (size_t)img * a.side * a.side * 3;
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+            const int idx = k * NT + tid;
+            const int wr = idx / WIN_C, wc = idx - wr * WIN_C;
+            const int y = r0 + wr, x = c0 + wc;
+            const bool ok = idx < WIN_R * WIN_C && (unsigned)y < (unsigned)a.side && (unsigned)x < (unsigned)a.side;
+            const float* s3 = base + ((size_t)(ok ? y : 0) * a.side + (ok ? x : 0)) * 3;
+            rawpx[k][0] = ok ? s3[0] : 0.f; rawpx[k][1] = ok ? s3[1] : 0.f; rawpx[k][2] = ok ? s3[2] : 0.f;
+        }
+    };
+    auto raw_commit = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+            const int idx = k * NT + tid;
+            if (idx < WIN_R * WIN_C) {
+                half4_t v = {(half_t)rawpx[k][0], (half_t)rawpx[k][1], (half_t)rawpx[k][2], (half_t)0};
+                *reinterpret_cast<half4_t*>(smem + WIN_OFF + buf * WIN_BYTES + idx * 8) = v;
+            }
+        }
+    };
+
     // Window k is requested at the top of iteration k-2 (windows 0 and 1 up front).  VMEM operations of this
     // wave younger than window `it` when iteration `it` starts: the PS pooled stores of each iteration since the
     // request, and the DMA instructions of window it+1 (nw per wave) if that window exists.
     const int nw = (WIN_INSTR - wave + NW - 1) / NW;
-    issue_window(p, 0);
-    if (p + G < a.n_patches) issue_window(p + G, 1);
+    if constexpr (RAW) {
+        raw_fetch(p);
+        raw_commit(0);
+    } else {
+        issue_window(p, 0);
+        if (p + G < a.n_patches) issue_window(p + G, 1);
+    }
     int buf = 0;
     for (int it = 0;; ++it, p += G) {
-        {
+        if constexpr (!RAW) {
             const int next_dma = p + G < a.n_patches ? nw : 0;
             sp_wait_vm_dyn((it == 0 ? 0 : it == 1 ? PS : 2 * PS) + next_dma);
         }
         sp_barrier();
-        if (p + 2 * G < a.n_patches) issue_window(p + 2 * G, buf + 2 >= NBUF ? buf + 2 - NBUF : buf + 2);
+        if constexpr (RAW) {
+            if (p + G < a.n_patches) raw_fetch(p + G);
+        } else {
+            if (p + 2 * G < a.n_patches) issue_window(p + 2 * G, buf + 2 >= NBUF ? buf + 2 - NBUF : buf + 2);
+        }
 
         const int img = p / (ppr * ppr);
         const int rem = p - img * ppr * ppr;
@@ -282,6 +324,7 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
         }
         if (p + G >= a.n_patches) break;
         buf = buf + 1 == NBUF ? 0 : buf + 1;
+        if constexpr (RAW) raw_commit(buf);      // last read by the conv of iteration it-2: two barriers ago
     }
 }
 
@@ -295,7 +338,7 @@ bool stem_pool_f16_supported(int side, int base_width) {
     return enabled && base_width == 64 && side % 32 == 0 && side >= 32;
 }
 
-template <int NSPLIT>
+template <int NSPLIT, bool RAW>
 static int launch_sp(const StemPoolArgs& a, hipStream_t stream);
 
 int launch_stem_pool_f16(const void* prepped, const void* w, const float* bias, void* out, int n, int side,
@@ -309,14 +352,35 @@ int launch_stem_pool_f16(const void* prepped, const void* w, const float* bias, 
     a.n = n; a.side = side;
     const int ppr = side / 4 / sp::PP;
     a.n_patches = n * ppr * ppr;
+    a.img_f32 = nullptr;
     static const int split = sp_env_int("METRO_STEM_SPLIT", 2);
-    if (split == 2) return launch_sp<2>(a, stream);
-    return launch_sp<1>(a, stream);
+    if (split == 2) return launch_sp<2, false>(a, stream);
+    return launch_sp<1, false>(a, stream);
 }
 
-template <int NSPLIT>
+bool stem_pool_f32in_supported(int side, int base_width) {
+    static const int enabled = sp_env_int("METRO_STEM_RAW", 1);
+    return enabled && stem_pool_f16_supported(side, base_width);
+}
+
+int launch_stem_pool_f32in(const float* images, const void* w, const float* bias, void* out, int n, int side,
+                           hipStream_t stream) {
+    if (!stem_pool_f32in_supported(side, 64)) { set_error("stem_pool_f32in: unsupported shape (side %d)", side); return METRO_ERR_INVALID_ARG; }
+    StemPoolArgs a;
+    a.img_f32 = images;
+    a.img = nullptr;
+    a.w = static_cast<const half_t*>(w);
+    a.bias = bias;
+    a.out = static_cast<half_t*>(out);
+    a.n = n; a.side = side;
+    const int ppr = side / 4 / sp::PP;
+    a.n_patches = n * ppr * ppr;
+    return launch_sp<2, true>(a, stream);
+}
+
+template <int NSPLIT, bool RAW>
 static int launch_sp(const StemPoolArgs& a, hipStream_t stream) {
-    auto kern = stem_pool_f16_kernel<NSPLIT>;
+    auto kern = stem_pool_f16_kernel<NSPLIT, RAW>;
     constexpr int NT = 64 * sp::MG * NSPLIT;
     static int grid_cap = 0;
     if (grid_cap == 0) {

@@ -201,7 +201,7 @@ def test_race_screen_repeated_runs_are_bit_identical(cuda):
         assert torch.equal(out, ref), f'launch {i} differs: max |d| {(out - ref).abs().max().item()}'
     # layer outputs too (a wrong tile can be averaged away by the soft-argmax)
     n_layers = len(eng.layer_infos())
-    for li in (1, 5, 6, 20, 30, 45, 50, n_layers - 2):
+    for li in sorted({0, 1, 5, 6, 20, 30, 45, n_layers - 3, n_layers - 2}):
         a = eng.forward_upto(x, li)
         for _ in range(5):
             assert torch.equal(eng.forward_upto(x, li), a), f'layer {li} not deterministic'

@@ -194,6 +194,11 @@ def test_stem_pool_f16(lib, cuda, n, side):
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max()
     assert (got == want).mean() > 0.98
+    # reading the fp32 crops directly (cast + border inside the kernel) gives the same bits
+    out2 = torch.full_like(out, float('nan'))
+    check(lib.metro_stem_pool_f32in(H.ptr(timg), H.ptr(tw), H.ptr(tb), H.ptr(out2), n, side, None), 'metro_stem_pool_f32in')
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
 
 
 def test_fused_entry_points_reject_unsupported_shapes(lib, cuda):
