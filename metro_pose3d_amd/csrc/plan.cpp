@@ -470,7 +470,7 @@ int build_plan(MetroPlan* p) {
     for (int s = 0; s < S_COUNT; ++s) {
         p->slot_offset[s] = off;
         int64_t bytes = p->slot_bytes_per_image[s] * p->max_batch;
-        if (s == S_PART) bytes = (int64_t)(512 + p->max_batch) * sp.n_joints_head * 5 * sizeof(double);
+        if (s == S_PART) bytes = softargmax_scratch_bytes(p->max_batch, sp.proc_side / sp.stride, sp.n_joints_head);
         off = align_up(off + bytes, 256);
     }
     p->workspace_bytes = off;

@@ -200,10 +200,13 @@ int launch_maxpool(const void* in, void* out, int n, int h_in, int w_in, int c, 
 constexpr int SA_NT = 256;
 
 int softargmax_slabs(int n, int side) {
-    // enough blocks to cover 256 CUs about twice, but no slab smaller than 8 pixels
+    // Slabs of >= 32 pixels, at most 64 per image.  Deliberately independent of the batch size: the fp32 partial
+    // sums are folded slab by slab, so a crop's pose has the same bits whatever batch it arrives in (no op of the
+    // path crosses the batch dimension).  Batch 64 at stride 16: 8 slabs x 64 images = 512 blocks.
+    (void)n;
     const int pixels = side * side;
-    int slabs = (512 + n - 1) / n;
-    if (slabs > pixels / 8) slabs = pixels / 8;
+    int slabs = pixels / 32;
+    if (slabs > 64) slabs = 64;
     if (slabs < 1) slabs = 1;
     return slabs;
 }

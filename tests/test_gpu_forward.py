@@ -163,6 +163,21 @@ def test_batch_independence_bit_exact(cuda):
         assert torch.equal(whole, parts)
 
 
+def test_batch_independence_full_width_persistent_kernels(cuda):
+    """Full base width (the persistent kernels walk tiles of several images per block, the stem kernel patches):
+    how tiles are dealt to blocks changes with the batch, the per-pixel arithmetic must not (the soft-argmax slab
+    partition is batch independent for the same reason).  70 crops = more tiles than resident blocks in every
+    persistent kernel; sub-batches of 1, 5 and 64 give the same bits."""
+    spec = ModelSpec(50, 16, 'h36m')
+    params, images = _setup(spec, 70, gain=synth.logit_gain_for(50, 16))
+    x = torch.from_numpy(images).to(cuda)
+    eng = Engine(spec, params, 'f16', max_batch=70, device=cuda)
+    whole = eng.forward(x).clone()
+    assert torch.isfinite(whole).all()
+    parts = torch.cat([eng.forward(x[:1]).clone(), eng.forward(x[1:6]).clone(), eng.forward(x[6:]).clone()])
+    assert torch.equal(whole, parts)
+
+
 def test_estimate_pose_boundary(cuda, tmp_path):
     """Same call shape as reference inference.py:31-43."""
     from metro_pose3d_amd import save_model
