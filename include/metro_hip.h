@@ -236,6 +236,32 @@ int  metro_eval_metrics(const float* d_pred, const float* d_true, const uint8_t*
                         int32_t n_joints, float threshold_mm, float* d_dist, float* d_dist_aligned,
                         double* d_sums, void* stream);
 
+/* ---- alternative decode heads, the step AFTER the path ---- */
+/* Soft-argmax coordinates in [0,1], head joint order, (x,y,z): the `coords3d` that
+ * net_output_to_heatmap_and_coords returns (reference src/model/volumetric.py:227-235), i.e. metro_softargmax
+ * without heatmap_to_metric / root_relative / gather.  d_coords01_out fp32 [n, n_joints_head, 3]. */
+int  metro_softargmax01(const void* d_logits, int32_t n, const MetroSpec* spec, int32_t precise, void* d_scratch,
+                        float* d_coords01_out, void* stream);
+/* `--scale-recovery=bone-lengths` / `bone-lengths-true` (volumetric.py:171-191): heatmap_to_image (:288-295),
+ * rays = inv_intrinsics . [u,v,1] (:221-222), delta_z = (z - z_root) * box_size, per-pose z offset by the
+ * reference's scipy Levenberg-Marquardt solve (src/model/bone_length_based_backproj.py:38-62; MINPACK lmder
+ * restated for one unknown, fp64), back_project (:284-285).  d_bone_lengths fp64 [n_edges] (dataset means) or
+ * [n, n_edges] when per_pose_lengths != 0; d_edges int32 [n_edges, 2] head joint indices.  root_relative != 0
+ * subtracts the last head joint (tfu3d.py:23-25); permute != 0 gathers spec->permutation (main.py:119-127).
+ * d_coords3d_out fp32 [n, J, 3]; d_z_offset_out fp32 [n] or NULL. */
+int  metro_backproject_bone_lengths(const float* d_coords01, const float* d_inv_intrinsics, const double* d_bone_lengths,
+                                    int32_t per_pose_lengths, const int32_t* d_edges, int32_t n_edges, int32_t n,
+                                    const MetroSpec* spec, int32_t root_relative, int32_t permute,
+                                    float* d_coords3d_out, float* d_z_offset_out, void* stream);
+/* `--scale-recovery=true-root-depth` (volumetric.py:192-199): the same with a given root depth [n] fp32. */
+int  metro_backproject_root_depth(const float* d_coords01, const float* d_inv_intrinsics, const float* d_root_z,
+                                  int32_t n, const MetroSpec* spec, int32_t root_relative, int32_t permute,
+                                  float* d_coords3d_out, void* stream);
+/* to_orig_cam (volumetric.py:277-281): x' = R x per joint, joints swapped with their mirror joint when
+ * det(R) <= 0.  d_rot fp32 [n,9] row-major, d_mirror int32 [n_joints]. */
+int  metro_to_orig_cam(const float* d_coords, const float* d_rot, const int32_t* d_mirror, float* d_out, int32_t n,
+                       int32_t n_joints, void* stream);
+
 const char* metro_last_error(void);
 int32_t metro_abi_version(void);
 

@@ -84,6 +84,11 @@ SIGNATURES = {
     'metro_maxpool3x3s2_zeropad': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                              C.c_int32, _P]),
     'metro_softargmax_scratch_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'metro_softargmax01': (C.c_int, [_P, C.c_int32, C.POINTER(MetroSpec), C.c_int32, _P, _P, _P]),
+    'metro_backproject_bone_lengths': (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.POINTER(MetroSpec),
+                                                 C.c_int32, C.c_int32, _P, _P, _P]),
+    'metro_backproject_root_depth': (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(MetroSpec), C.c_int32, C.c_int32, _P, _P]),
+    'metro_to_orig_cam': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     'metro_softargmax': (C.c_int, [_P, C.c_int32, C.POINTER(MetroSpec), C.c_int32, _P, _P, _P]),
     'metro_last_error': (C.c_char_p, []),
     'metro_abi_version': (C.c_int32, []),

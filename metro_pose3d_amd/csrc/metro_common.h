@@ -139,7 +139,12 @@ struct SoftArgmaxArgs {
 int softargmax_slabs(int n, int side);
 int64_t softargmax_scratch_bytes(int n, int side, int n_joints_head);
 int launch_softargmax(const void* logits, const SoftArgmaxArgs& a, int precise, void* partials,
-                      float* poses_out, hipStream_t stream);
+                      float* poses_out, hipStream_t stream, float* coords01_out = nullptr);
+// alternative decode heads (heads.hip): root_z != NULL selects true-root-depth, else the bone-length solve
+int launch_backproject(const float* coords01, const float* inv_k, const double* targets, int per_pose_targets,
+                       const float* root_z, const int* edges, int n, int nj, int ne, const MetroSpec& spec,
+                       int root_relative, int permute, float* out, float* z_out, hipStream_t stream);
+int launch_to_orig_cam(const float* x, const float* rot, const int* mirror, float* out, int n, int nj, hipStream_t stream);
 SoftArgmaxArgs make_softargmax_args(const MetroSpec& spec, int n);
 
 }  // namespace metro

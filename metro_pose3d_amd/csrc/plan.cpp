@@ -826,6 +826,53 @@ int metro_softargmax(const void* d_logits, int32_t n, const MetroSpec* spec, int
     return launch_softargmax(d_logits, a, precise, d_partials, d_poses_out, static_cast<hipStream_t>(stream));
 }
 
+int metro_softargmax01(const void* d_logits, int32_t n, const MetroSpec* spec, int32_t precise, void* d_partials,
+                       float* d_coords01_out, void* stream) {
+    METRO_CHECK_ARG(d_logits && spec && d_partials && d_coords01_out && n > 0, "softargmax01: bad argument");
+    METRO_CHECK_ARG(spec->n_joints_head >= 1 && spec->n_joints_head <= METRO_MAX_JOINTS, "softargmax01: joint count out of range");
+    METRO_CHECK_ARG(spec->proc_side / spec->stride >= 2, "softargmax01: heat-map side must be >= 2");
+    const SoftArgmaxArgs a = make_softargmax_args(*spec, n);
+    return launch_softargmax(d_logits, a, precise, d_partials, nullptr, static_cast<hipStream_t>(stream), d_coords01_out);
+}
+
+static int check_head_args(const MetroSpec* spec, int32_t n, int32_t n_edges, const char* what) {
+    METRO_CHECK_ARG(spec != nullptr && n > 0, "%s: bad argument", what);
+    METRO_CHECK_ARG(spec->n_joints_head >= 1 && spec->n_joints_head <= 64 && spec->n_joints_out >= 1 &&
+                        spec->n_joints_out <= 64, "%s: joint counts out of range (<= 64)", what);
+    METRO_CHECK_ARG(n_edges >= 0 && n_edges <= 64, "%s: at most 64 stick-figure edges (got %d)", what, n_edges);
+    return METRO_OK;
+}
+
+int metro_backproject_bone_lengths(const float* d_coords01, const float* d_inv_intrinsics, const double* d_bone_lengths,
+                                   int32_t per_pose_lengths, const int32_t* d_edges, int32_t n_edges, int32_t n,
+                                   const MetroSpec* spec, int32_t root_relative, int32_t permute, float* d_coords3d_out,
+                                   float* d_z_offset_out, void* stream) {
+    int st = check_head_args(spec, n, n_edges, "backproject_bone_lengths");
+    if (st) return st;
+    METRO_CHECK_ARG(d_coords01 && d_inv_intrinsics && d_bone_lengths && d_edges && d_coords3d_out && n_edges >= 1,
+                    "backproject_bone_lengths: NULL tensor pointer or no edges");
+    return launch_backproject(d_coords01, d_inv_intrinsics, d_bone_lengths, per_pose_lengths != 0, nullptr, d_edges, n,
+                              spec->n_joints_head, n_edges, *spec, root_relative, permute, d_coords3d_out, d_z_offset_out,
+                              static_cast<hipStream_t>(stream));
+}
+
+int metro_backproject_root_depth(const float* d_coords01, const float* d_inv_intrinsics, const float* d_root_z, int32_t n,
+                                 const MetroSpec* spec, int32_t root_relative, int32_t permute, float* d_coords3d_out,
+                                 void* stream) {
+    int st = check_head_args(spec, n, 0, "backproject_root_depth");
+    if (st) return st;
+    METRO_CHECK_ARG(d_coords01 && d_inv_intrinsics && d_root_z && d_coords3d_out, "backproject_root_depth: NULL tensor pointer");
+    return launch_backproject(d_coords01, d_inv_intrinsics, nullptr, 0, d_root_z, nullptr, n, spec->n_joints_head, 0, *spec,
+                              root_relative, permute, d_coords3d_out, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int metro_to_orig_cam(const float* d_coords, const float* d_rot, const int32_t* d_mirror, float* d_out, int32_t n,
+                      int32_t n_joints, void* stream) {
+    METRO_CHECK_ARG(d_coords && d_rot && d_mirror && d_out && n > 0 && n_joints >= 1 && n_joints <= 64,
+                    "to_orig_cam: bad argument (1 <= joints <= 64)");
+    return launch_to_orig_cam(d_coords, d_rot, d_mirror, d_out, n, n_joints, static_cast<hipStream_t>(stream));
+}
+
 const char* metro_last_error(void) { return metro::get_error(); }
 int32_t metro_abi_version(void) { return METRO_ABI_VERSION; }
 

@@ -301,7 +301,8 @@ __global__ __launch_bounds__(SA_NT) void softargmax_partial_kernel(
 template <typename AccT>
 __global__ __launch_bounds__(64) void softargmax_finalize_kernel(const AccT* __restrict__ partials,
                                                                  float* __restrict__ poses,
-                                                                 SoftArgmaxArgs a, int slabs) {
+                                                                 SoftArgmaxArgs a, int slabs,
+                                                                 float* __restrict__ coords01) {
     __shared__ AccT mm[METRO_MAX_JOINTS][3];
     const int img = blockIdx.x;
     const int j = threadIdx.x;
@@ -321,13 +322,17 @@ __global__ __launch_bounds__(64) void softargmax_finalize_kernel(const AccT* __r
             }
         }
         const AccT x01 = SX / S, y01 = SY / S, z01 = SZ / S;
+        if (coords01 != nullptr) {            // net_output_to_heatmap_and_coords output (volumetric.py:234-235)
+            float* c = coords01 + ((size_t)img * nj + j) * 3;
+            c[0] = (float)x01; c[1] = (float)y01; c[2] = (float)z01;
+        }
         // heatmap_to_metric: (c * lrc + half) * box / proc_side ; z * box  (volumetric.py:288-306)
         mm[j][0] = (x01 * (AccT)a.lrc + (AccT)a.half_off) * (AccT)a.box_size_mm / (AccT)a.proc_side;
         mm[j][1] = (y01 * (AccT)a.lrc + (AccT)a.half_off) * (AccT)a.box_size_mm / (AccT)a.proc_side;
         mm[j][2] = z01 * (AccT)a.box_size_mm;
     }
     __syncthreads();
-    if (j < a.n_joints_out) {
+    if (poses != nullptr && j < a.n_joints_out) {
         const int src = a.perm[j];
         float* o = poses + ((size_t)img * a.n_joints_out + j) * 3;
 #pragma unroll
@@ -353,7 +358,7 @@ SoftArgmaxArgs make_softargmax_args(const MetroSpec& spec, int n) {
 
 template <typename AccT, typename LogitT>
 static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void* partials,
-                               float* poses, hipStream_t stream) {
+                               float* poses, float* coords01, hipStream_t stream) {
     const int C = a.depth * a.n_joints_head;
     const int quads = C / 4;
     const int ppb = SA_NT / quads;
@@ -374,20 +379,20 @@ static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void
     int st = launch_status("softargmax_partial");
     if (st) return st;
     hipLaunchKernelGGL(softargmax_finalize_kernel<AccT>, dim3(a.n), dim3(64), 0, stream,
-                       static_cast<const AccT*>(partials), poses, a, slabs);
+                       static_cast<const AccT*>(partials), poses, a, slabs, coords01);
     return launch_status("softargmax_finalize");
 }
 
 int launch_softargmax(const void* logits, const SoftArgmaxArgs& a, int precise, void* partials,
-                      float* poses_out, hipStream_t stream) {
+                      float* poses_out, hipStream_t stream, float* coords01_out) {
     const int C = a.depth * a.n_joints_head;
     if (C % 4 || C / 4 > SA_NT || a.n_joints_head > METRO_MAX_JOINTS || a.n_joints_out > 64) {
         set_error("softargmax: unsupported head (depth %d, joints %d)", a.depth, a.n_joints_head);
         return METRO_ERR_UNSUPPORTED;
     }
-    if (precise == 0) return launch_softargmax_t<float, float>(logits, a, partials, poses_out, stream);
-    if (precise == 1) return launch_softargmax_t<double, float>(logits, a, partials, poses_out, stream);
-    if (precise == 2) return launch_softargmax_t<double, double>(logits, a, partials, poses_out, stream);
+    if (precise == 0) return launch_softargmax_t<float, float>(logits, a, partials, poses_out, coords01_out, stream);
+    if (precise == 1) return launch_softargmax_t<double, float>(logits, a, partials, poses_out, coords01_out, stream);
+    if (precise == 2) return launch_softargmax_t<double, double>(logits, a, partials, poses_out, coords01_out, stream);
     set_error("softargmax: precise must be 0, 1 or 2 (got %d)", precise);
     return METRO_ERR_INVALID_ARG;
 }

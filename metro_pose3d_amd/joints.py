@@ -35,6 +35,14 @@ class Skeleton:
     permutation: Tuple[int, ...]     # output row i = head joint permutation[i]
     names: Tuple[str, ...]           # `joint_names` output
     edges: Tuple[Tuple[int, int], ...]  # `joint_edges` output (indices into `names`)
+    head_edges: Tuple[Tuple[int, int], ...] = ()   # stick-figure edges in head order (bone-length heads)
+
+    @property
+    def head_mirror(self) -> Tuple[int, ...]:
+        """index of the opposite-side joint, head order (reference datasets.py:77-80,94-100)."""
+        idx = {n: i for i, n in enumerate(self.head_names)}
+        other = lambda n: ('r' + n[1:]) if n.startswith('l') else ('l' + n[1:]) if n.startswith('r') else n
+        return tuple(idx[other(n)] for n in self.head_names)
 
     @property
     def n_head(self) -> int:
@@ -55,7 +63,7 @@ def _make(head: List[str], head_edges: List[Tuple[int, int]], perm: List[int]) -
     position_of = {h: i for i, h in enumerate(perm)}   # head index -> output row
     names = tuple(head[h] for h in perm)
     edges = tuple((position_of[a], position_of[b]) for a, b in head_edges)
-    return Skeleton(tuple(head), tuple(perm), names, edges)
+    return Skeleton(tuple(head), tuple(perm), names, edges, tuple((int(a), int(b)) for a, b in head_edges))
 
 
 def skeleton(dataset: str) -> Skeleton:

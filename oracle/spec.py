@@ -132,6 +132,9 @@ class OracleJointInfo:
         else:
             self.edges = [tuple(e) for e in edges]
         self.n_joints = len(self.names)
+        # index of the joint on the opposite side (datasets.py:77-80, other_side_joint_name :94-100)
+        other = lambda n: ('r' + n[1:]) if n.startswith('l') else ('l' + n[1:]) if n.startswith('r') else n
+        self.mirror_mapping = [ids[other(n)] for n in self.names]
 
     def permute(self, permutation: Sequence[int]) -> 'OracleJointInfo':
         """datasets.py:104-108 with util.invert_permutation (util.py:483-484).
