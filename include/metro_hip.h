@@ -257,6 +257,8 @@ int  metro_backproject_bone_lengths(const float* d_coords01, const float* d_inv_
 int  metro_backproject_root_depth(const float* d_coords01, const float* d_inv_intrinsics, const float* d_root_z,
                                   int32_t n, const MetroSpec* spec, int32_t root_relative, int32_t permute,
                                   float* d_coords3d_out, void* stream);
+/* heatmap_to_25d (volumetric.py:298-300): (x, y) in crop pixels via heatmap_to_image, z * box_size_mm; head order. */
+int  metro_heatmap_to_25d(const float* d_coords01, int32_t n, const MetroSpec* spec, float* d_out, void* stream);
 /* to_orig_cam (volumetric.py:277-281): x' = R x per joint, joints swapped with their mirror joint when
  * det(R) <= 0.  d_rot fp32 [n,9] row-major, d_mirror int32 [n_joints]. */
 int  metro_to_orig_cam(const float* d_coords, const float* d_rot, const int32_t* d_mirror, float* d_out, int32_t n,

@@ -89,6 +89,7 @@ SIGNATURES = {
                                                  C.c_int32, C.c_int32, _P, _P, _P]),
     'metro_backproject_root_depth': (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(MetroSpec), C.c_int32, C.c_int32, _P, _P]),
     'metro_to_orig_cam': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
+    'metro_heatmap_to_25d': (C.c_int, [_P, C.c_int32, C.POINTER(MetroSpec), _P, _P]),
     'metro_softargmax': (C.c_int, [_P, C.c_int32, C.POINTER(MetroSpec), C.c_int32, _P, _P, _P]),
     'metro_last_error': (C.c_char_p, []),
     'metro_abi_version': (C.c_int32, []),

@@ -292,6 +292,26 @@ int launch_backproject(const float* coords01, const float* inv_k, const double* 
     return launch_status("backproject");
 }
 
+// heatmap_to_25d (volumetric.py:298-300): image-pixel x, y and z * box_size per head joint
+__global__ __launch_bounds__(256) void heatmap_to_25d_kernel(const float* __restrict__ c01, float* __restrict__ out, int total,
+                                                             float lrc, float half_off, float box) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // one (pose, joint)
+    if (i >= total) return;
+    float u = c01[i * 3 + 0] * lrc, v = c01[i * 3 + 1] * lrc;
+    out[i * 3 + 0] = u + half_off;
+    out[i * 3 + 1] = v + half_off;
+    out[i * 3 + 2] = c01[i * 3 + 2] * box;
+}
+
+int launch_heatmap_to_25d(const float* coords01, float* out, int n, const MetroSpec& spec, hipStream_t stream) {
+    const int last = spec.proc_side - 1;
+    const int total = n * spec.n_joints_head;
+    hipLaunchKernelGGL(heatmap_to_25d_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, coords01, out, total,
+                       (float)(last - (last % spec.stride) - 1), spec.centered_stride ? (float)(spec.stride / 2) : 0.0f,
+                       spec.box_size_mm);
+    return launch_status("heatmap_to_25d");
+}
+
 int launch_to_orig_cam(const float* x, const float* rot, const int* mirror, float* out, int n, int nj, hipStream_t stream) {
     hipLaunchKernelGGL(to_orig_cam_kernel, dim3(n), dim3(64), 0, stream, x, rot, mirror, out, n, nj);
     return launch_status("to_orig_cam");

@@ -144,6 +144,7 @@ int launch_softargmax(const void* logits, const SoftArgmaxArgs& a, int precise, 
 int launch_backproject(const float* coords01, const float* inv_k, const double* targets, int per_pose_targets,
                        const float* root_z, const int* edges, int n, int nj, int ne, const MetroSpec& spec,
                        int root_relative, int permute, float* out, float* z_out, hipStream_t stream);
+int launch_heatmap_to_25d(const float* coords01, float* out, int n, const MetroSpec& spec, hipStream_t stream);
 int launch_to_orig_cam(const float* x, const float* rot, const int* mirror, float* out, int n, int nj, hipStream_t stream);
 SoftArgmaxArgs make_softargmax_args(const MetroSpec& spec, int n);
 

@@ -866,6 +866,13 @@ int metro_backproject_root_depth(const float* d_coords01, const float* d_inv_int
                               root_relative, permute, d_coords3d_out, nullptr, static_cast<hipStream_t>(stream));
 }
 
+int metro_heatmap_to_25d(const float* d_coords01, int32_t n, const MetroSpec* spec, float* d_out, void* stream) {
+    int st = check_head_args(spec, n, 0, "heatmap_to_25d");
+    if (st) return st;
+    METRO_CHECK_ARG(d_coords01 && d_out, "heatmap_to_25d: NULL tensor pointer");
+    return launch_heatmap_to_25d(d_coords01, d_out, n, *spec, static_cast<hipStream_t>(stream));
+}
+
 int metro_to_orig_cam(const float* d_coords, const float* d_rot, const int32_t* d_mirror, float* d_out, int32_t n,
                       int32_t n_joints, void* stream) {
     METRO_CHECK_ARG(d_coords && d_rot && d_mirror && d_out && n > 0 && n_joints >= 1 && n_joints <= 64,

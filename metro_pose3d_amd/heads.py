@@ -5,6 +5,7 @@ through the C ABI (csrc/heads.hip).  Names and argument meaning follow the refer
   backproject_bone_lengths  scale_recovery 'bone-lengths' / '-true'   volumetric.py:171-191,
                             optimize_z_offset_by_bones(_tensor)       src/model/bone_length_based_backproj.py:15-62
   backproject_root_depth    scale_recovery 'true-root-depth'          volumetric.py:192-199
+  heatmap_to_25d            crop pixels + z * box_size                volumetric.py:298-300
   to_orig_cam               rotation + mirror on det(R) <= 0          volumetric.py:277-281
 
 MeTRo's own output (`scale_recovery == 'metro'`, volumetric.py:200-201) is `Engine.forward` / `estimate_pose`.
@@ -91,6 +92,17 @@ def backproject_root_depth(coords01: torch.Tensor, inv_intrinsics, root_z, spec:
     out = torch.empty((n, spec.skeleton.n_out if permute else spec.skeleton.n_head, 3), dtype=torch.float32, device=dev)
     check(lib.metro_backproject_root_depth(_p(c), _p(k), _p(rz), n, C.byref(cs), int(root_relative), int(permute), _p(out),
                                            _stream(dev)), 'metro_backproject_root_depth')
+    return out
+
+
+def heatmap_to_25d(coords01: torch.Tensor, spec: ModelSpec) -> torch.Tensor:
+    """heatmap_to_25d (volumetric.py:298-300): [N,J,3] in [0,1] -> (x px, y px, z mm), head order."""
+    lib = _lib.load()
+    dev = coords01.device
+    c = _f32(coords01, dev, (spec.skeleton.n_head, 3))
+    cs = spec.to_c(1)
+    out = torch.empty_like(c)
+    check(lib.metro_heatmap_to_25d(_p(c), c.shape[0], C.byref(cs), _p(out), _stream(dev)), 'metro_heatmap_to_25d')
     return out
 
 

@@ -29,6 +29,13 @@ def heatmap_to_image(coords01_xy: np.ndarray, stride: int, proc_side: int = 256,
     return out.astype(np.float32)
 
 
+def heatmap_to_25d(coords01, stride, proc_side=256, centered=True, box_size_mm=2200.0):
+    """volumetric.py:298-300."""
+    c = np.asarray(coords01, np.float32)
+    return np.concatenate([heatmap_to_image(c[..., :2], stride, proc_side, centered),
+                           c[..., 2:] * np.float32(box_size_mm)], axis=-1).astype(np.float32)
+
+
 def camcoords_and_delta_z(coords01, inv_intrinsics, stride, proc_side=256, centered=True, box_size_mm=2200.0):
     c = np.asarray(coords01, np.float32)
     k = np.asarray(inv_intrinsics, np.float32)

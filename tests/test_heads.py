@@ -131,6 +131,8 @@ def test_gpu_coords01_and_to_orig_cam(cuda):
     ref = soft_argmax01(torch.from_numpy(logits).permute(0, 3, 1, 2).double(), spec.skeleton.n_head, spec.depth)[1].numpy()
     assert got.shape == ref.shape == (5, 17, 3)
     assert np.abs(got - ref).max() <= 1e-6
+    c01 = rng.uniform(0, 1, (7, 17, 3)).astype(np.float32)
+    assert np.array_equal(MH.heatmap_to_25d(torch.from_numpy(c01).to(cuda), spec).cpu().numpy(), OH.heatmap_to_25d(c01, spec.stride))
     ji = head_joint_info('h36m')
     x = rng.normal(0, 500, (6, 17, 3)).astype(np.float32)
     q, _ = np.linalg.qr(rng.normal(size=(6, 3, 3)))
