@@ -48,8 +48,11 @@ __device__ __forceinline__ void slab_wait_barrier() {
 }
 
 // WM: 32-row cout tiles per wave (TM = WAVES_M*WM*32); pixels: TN = 256 = WAVES_N * WN * 32
-template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int SLAB_ROWS_, int SLAB_BUFS_ = 2>
+// TPS: taps per K step.  1 = one (chunk, tap) per barrier; 3 = one kernel ROW (3 taps) per barrier for the
+// 64-cout tiles, whose 8 MFMAs per wave per tap are too few to amortise the barrier + fragment-read latency.
+template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int SLAB_ROWS_, int SLAB_BUFS_ = 2, int TPS_ = 1>
 struct SlabCfg {
+    static constexpr int TPS = TPS_;
     static constexpr int SLAB_BUFS = SLAB_BUFS_;             // 1: single-chunk layers (c_in == 64): half the LDS, 2 blocks/CU
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM = WM_, WN = WN_;
     static constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
@@ -60,13 +63,14 @@ struct SlabCfg {
     static constexpr int SLAB_BYTES = SLAB_ROWS * 128;
     static constexpr int ZERO_OFF = SLAB_BUFS * SLAB_BYTES;  // 256-byte zero area behind the slab(s)
     static constexpr int W_OFF = ZERO_OFF + 256;
-    static constexpr int W_STAGE_BYTES = TM * 128;
+    static constexpr int W_STAGE_BYTES = TPS * TM * 128;
     static constexpr int W_STAGES = 3;
     static constexpr int RAW_BYTES = W_OFF + W_STAGES * W_STAGE_BYTES;
     static constexpr int OUT_ROW_BYTES = TM * 2 + 16;
     static constexpr int OUT_BYTES = TN * OUT_ROW_BYTES;
     static constexpr int LDS_BYTES = RAW_BYTES > OUT_BYTES ? RAW_BYTES : OUT_BYTES;
     static_assert(TN == 256, "slab kernel tiles 256 pixels");
+    static_assert(TPS == 1 || TPS == 3, "one tap or one kernel row per step");
     static_assert(SLAB_ROWS % (8 * NW) == 0 && TM % (8 * NW) == 0, "loader mismatch");
     // the epilogue tile overlays slabs + zero area + weight ring (all idle by then)
 };
@@ -154,14 +158,17 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
         }
         (void)last_part;
     };
-    // issues W of the step whose (tap) is `t_issue`, into ring slot `slot`
-    auto issue_w_part = [&](int slot, int t_issue, int part) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + Cfg::W_OFF + slot * Cfg::W_STAGE_BYTES + wave * 8 * 128);
+    // issues W of the step whose first tap is `t_issue` (TPS taps: t_issue .. t_issue+TPS-1), into ring slot `slot`;
+    // `tt` = which of those taps, `part` = quarter of its instructions; pointers advance after the last piece
+    auto issue_w_part = [&](int slot, int t_issue, int part, int tt = 0) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + Cfg::W_OFF + slot * Cfg::W_STAGE_BYTES +
+                                                             tt * Cfg::TM * 128 + wave * 8 * 128);
 #pragma unroll
         for (int i = 0; i < Cfg::WI; ++i) {
             if ((i & 3) != part) continue;
-            slab_dma16(wptr[i], base + i * NW * 8 * 128);
-            wptr[i] += wvalid[i] ? (t_issue == 8 ? w_chunk_inc : w_tap_inc) : 0;
+            slab_dma16(wptr[i] + (wvalid[i] ? tt * w_tap_inc : 0), base + i * NW * 8 * 128);
+            if (tt == Cfg::TPS - 1)
+                wptr[i] += wvalid[i] ? (t_issue + Cfg::TPS == 9 ? w_chunk_inc + (Cfg::TPS - 1) * w_tap_inc : Cfg::TPS * w_tap_inc) : 0;
         }
     };
 
@@ -195,55 +202,70 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
 #pragma unroll
     for (int p = 0; p < 4; ++p) issue_slab_part(0, p, false);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) issue_w_part(0, 0, p);
+    for (int tt = 0; tt < Cfg::TPS; ++tt)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) issue_w_part(1, 1, p);
+        for (int p = 0; p < 4; ++p) issue_w_part(0, 0, p, tt);
+#pragma unroll
+    for (int tt = 0; tt < Cfg::TPS; ++tt)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) issue_w_part(1, Cfg::TPS, p, tt);
     __syncthreads();   // zero area visible (plain ds_write above); DMA unaffected (asm, uncounted)
 
     // One (chunk, tap) step.  TAP, the ring slot and what gets issued are compile-time, so each
     // step is straight-line code: 16 ds_read_b128 + 16 MFMA + its share of the DMA issue.
     auto step = [&](auto tap_c, auto issue_slab_c, auto issue_w_c, auto wait_c, int slab_buf, int wslot) {
-        constexpr int TAP = decltype(tap_c)::value;
+        constexpr int TAP0 = decltype(tap_c)::value;             // first tap of the step
         slab_wait_barrier<decltype(wait_c)::value>();
         const char* wl = smem + Cfg::W_OFF + wslot * Cfg::W_STAGE_BYTES;
         const char* sl = smem + slab_buf * Cfg::SLAB_BYTES;
         const char* zl = smem + Cfg::ZERO_OFF;
         const int islot = wslot == 0 ? 2 : wslot - 1;          // slot of step q+2 == slot of step q-1
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            half8_t af[Cfg::WM], bf[Cfg::WN];
-            const int chunk = kk * 2 + frag_half;
+        for (int tt = 0; tt < Cfg::TPS; ++tt) {
 #pragma unroll
-            for (int i = 0; i < Cfg::WM; ++i) {
-                const int row = (wave_m * Cfg::WM + i) * 32 + frag_row;
-                af[i] = *reinterpret_cast<const half8_t*>(wl + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-            }
+            for (int kk = 0; kk < 4; ++kk) {
+                half8_t af[Cfg::WM], bf[Cfg::WN];
+                const int chunk = kk * 2 + frag_half;
 #pragma unroll
-            for (int j = 0; j < Cfg::WN; ++j) {
-                const int bo = boff[j][TAP];
-                const char* p = bo >= 0 ? sl + bo + ((chunk ^ ((bo >> 8) & 7)) << 4) : zl;
-                bf[j] = *reinterpret_cast<const half8_t*>(p);
-            }
+                for (int i = 0; i < Cfg::WM; ++i) {
+                    const int row = (wave_m * Cfg::WM + i) * 32 + frag_row;
+                    af[i] = *reinterpret_cast<const half8_t*>(wl + tt * Cfg::TM * 128 + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < Cfg::WN; ++j) {
+                    const int bo = boff[j][TAP0 + tt];
+                    const char* p = bo >= 0 ? sl + bo + ((chunk ^ ((bo >> 8) & 7)) << 4) : zl;
+                    bf[j] = *reinterpret_cast<const half8_t*>(p);
+                }
 #ifdef METRO_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-            for (int i = 0; i < Cfg::WM; ++i)
+                for (int i = 0; i < Cfg::WM; ++i)
 #pragma unroll
-                for (int j = 0; j < Cfg::WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < Cfg::WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
 #ifdef METRO_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(0);
 #endif
-            if constexpr (decltype(issue_slab_c)::value) issue_slab_part(slab_buf ^ 1, kk, kk == 3);
-            if constexpr (decltype(issue_w_c)::value) issue_w_part(islot, (TAP + 2) % 9, kk);
+                if constexpr (decltype(issue_slab_c)::value) {
+                    if (tt == 0) issue_slab_part(slab_buf ^ 1, kk, kk == 3);
+                }
+                if constexpr (decltype(issue_w_c)::value) issue_w_part(islot, (TAP0 + 2 * Cfg::TPS) % 9, kk, tt);
+            }
         }
     };
     using T = std::true_type;
     using F = std::false_type;
     auto I = [](auto v) { return v; };
-    // a whole chunk: 9 taps, slots cycle 0,1,2 (9 % 3 == 0 so every chunk starts on slot 0)
-    auto chunk_main = [&](int slab_buf) {       // not the last chunk: slab(c+1) at tap 0, W always
+    constexpr int WSI = Cfg::WI * Cfg::TPS;        // weight DMA instructions per wave per step
+    // a whole chunk: 9 taps in 9 / TPS steps, slots cycle 0,1,2 (every chunk starts on slot 0)
+    auto chunk_main = [&](int slab_buf) {       // not the last chunk: slab(c+1) during the first step, W always
+        if constexpr (Cfg::TPS == 3) {
+            step(std::integral_constant<int, 0>{}, T{}, T{}, std::integral_constant<int, WSI>{}, slab_buf, 0);
+            step(std::integral_constant<int, 3>{}, F{}, T{}, std::integral_constant<int, WSI + Cfg::SI>{}, slab_buf, 1);
+            step(std::integral_constant<int, 6>{}, F{}, T{}, std::integral_constant<int, WSI>{}, slab_buf, 2);
+        } else {
         step(std::integral_constant<int, 0>{}, T{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
         step(std::integral_constant<int, 1>{}, F{}, T{}, std::integral_constant<int, Cfg::WI + Cfg::SI>{}, slab_buf, 1);
         step(std::integral_constant<int, 2>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
@@ -253,8 +275,14 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
         step(std::integral_constant<int, 6>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
         step(std::integral_constant<int, 7>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
         step(std::integral_constant<int, 8>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
+        }
     };
     auto chunk_last = [&](int slab_buf) {       // last chunk: no slab, W stops two steps before the end
+        if constexpr (Cfg::TPS == 3) {
+            step(std::integral_constant<int, 0>{}, F{}, T{}, std::integral_constant<int, WSI>{}, slab_buf, 0);
+            step(std::integral_constant<int, 3>{}, F{}, F{}, std::integral_constant<int, WSI>{}, slab_buf, 1);
+            step(std::integral_constant<int, 6>{}, F{}, F{}, std::integral_constant<int, 0>{}, slab_buf, 2);
+        } else {
         step(std::integral_constant<int, 0>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
         step(std::integral_constant<int, 1>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
         step(std::integral_constant<int, 2>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
@@ -264,6 +292,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
         step(std::integral_constant<int, 6>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
         step(std::integral_constant<int, 7>{}, F{}, F{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
         step(std::integral_constant<int, 8>{}, F{}, F{}, std::integral_constant<int, 0>{}, slab_buf, 2);
+        }
     };
     (void)I; (void)nq;
     for (int c = 0; c + 1 < kc; ++c) chunk_main(c & 1);      // (kc > 1 requires SLAB_BUFS == 2: launcher)
@@ -340,6 +369,7 @@ using Slab128r384 = SlabCfg<2, 4, 2, 2, 384>;   // halo <= 64:  96 + 48 KiB
 using Slab64r320 = SlabCfg<1, 8, 2, 1, 320>;    //  64 cout x 256 px
 using Slab64r384 = SlabCfg<1, 8, 2, 1, 384>;
 using Slab64r512 = SlabCfg<1, 8, 2, 1, 512>;    // halo <= 128: 128 + 24 KiB
+using Slab64r320t3 = SlabCfg<1, 8, 2, 1, 320, 2, 3>;   // one kernel row per step: 80 + 72 KiB
 using Slab64r384b1 = SlabCfg<1, 8, 2, 1, 384, 1>;  // single chunk (c_in == 64), halo <= 64: 48 + 24 KiB -> 2 blocks / CU
 using Slab64r320b1 = SlabCfg<1, 8, 2, 1, 320, 1>;
 
@@ -373,6 +403,8 @@ int launch_conv3x3_slab(const MetroConvDesc& d, const void* in_, const void* w_,
     if (d.c_out <= 64 || blocks128 < 256) {
         if (d.c_in == 64 && halo <= 32) return launch_slab_cfg<Slab64r320b1>(a, in, w, bias, out, halo, stream);
         if (d.c_in == 64 && halo <= 64) return launch_slab_cfg<Slab64r384b1>(a, in, w, bias, out, halo, stream);
+        static const int t3 = [] { const char* e = getenv("METRO_SLAB_T3"); return e ? atoi(e) : 1; }();
+        if (t3 && halo <= 32) return launch_slab_cfg<Slab64r320t3>(a, in, w, bias, out, halo, stream);
         if (halo <= 32) return launch_slab_cfg<Slab64r320>(a, in, w, bias, out, halo, stream);
         if (halo <= 64) return launch_slab_cfg<Slab64r384>(a, in, w, bias, out, halo, stream);
         return launch_slab_cfg<Slab64r512>(a, in, w, bias, out, halo, stream);
