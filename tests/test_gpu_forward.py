@@ -222,6 +222,33 @@ def test_race_screen_repeated_runs_are_bit_identical(cuda):
             assert torch.equal(eng.forward_upto(x, li), a), f'layer {li} not deterministic'
 
 
+def test_race_screen_batch64_persistent_kernels(cuda):
+    """Same screen at the bench batch: every persistent block walks 4-16 tiles / 8 patches through its
+    double-buffered LDS-DMA rings with counted waits; bits must not depend on timing."""
+    spec = ModelSpec(50, 16, 'h36m')
+    params, images = _setup(spec, 64, gain=synth.logit_gain_for(50, 16))
+    x = torch.from_numpy(images).to(cuda)
+    eng = Engine(spec, params, 'f16', max_batch=64, device=cuda)
+    names = [li.name.decode() for li in eng.layer_infos()]
+    picks = [i for i, n in enumerate(names) if n in ('conv1+pool1', 'block1/unit_1/shortcut+conv1', 'block1/unit_1/conv3+unit_2/conv1',
+                                                     'block1/unit_3/conv3', 'block2/unit_2/conv3', 'block3/unit_2/conv2',
+                                                     'block3/unit_3/conv3', 'block4/unit_2/conv3', 'logits')]
+    assert len(picks) == 9
+    ref = eng.forward(x).clone()
+    refs = {i: eng.forward_upto(x, i).clone() for i in picks}
+    seconds = {i: eng.forward_upto(x, i, second=True).clone() for i in picks if eng.layer_infos()[i].out2_offset >= 0}
+    assert torch.isfinite(ref).all() and len(seconds) == 2
+    junk = torch.empty(256 << 20, dtype=torch.uint8, device=cuda)
+    for it in range(12):
+        if it % 2 == 0:
+            junk.fill_(it)
+        assert torch.equal(eng.forward(x), ref), f'launch {it} differs'
+        i = picks[it % len(picks)]
+        assert torch.equal(eng.forward_upto(x, i), refs[i]), f'layer {names[i]} not deterministic'
+        if i in seconds:
+            assert torch.equal(eng.forward_upto(x, i, second=True), seconds[i]), f'layer {names[i]} (second output) not deterministic'
+
+
 def test_hipgraph_replay_is_bit_identical(cuda, monkeypatch):
     """metro_plan_set_graph_max_batch: a captured forward replays to the same bits as plain launches."""
     spec = ModelSpec(50, 32, 'h36m', base_width=16)
