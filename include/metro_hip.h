@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define METRO_ABI_VERSION 2
+#define METRO_ABI_VERSION 3
 
 typedef enum MetroStatus {
     METRO_OK = 0,
@@ -100,6 +100,11 @@ typedef struct MetroLayerInfo {
     int64_t out2_offset;   /* fused launches with a second output tensor (shortcut+conv1 pairs,  */
     int32_t out2_channels; /*   conv3+next conv1): its workspace offset / channels; -1 / 0 = none */
     int32_t reserved;
+    /* algorithmic HBM bytes of this launch, every tensor it touches counted once (bench.py: the minimum the measured
+     * rocprofv3 FETCH_SIZE/WRITE_SIZE traffic is compared with): activations read + written per image (input, outputs,
+     * shortcut), and the parameter tensors it reads (once per launch, batch independent). */
+    int64_t algo_act_bytes_per_image;
+    int64_t algo_param_bytes;
 } MetroLayerInfo;
 
 /* ---- plan life cycle: replaces tf.import_graph_def of the frozen graph

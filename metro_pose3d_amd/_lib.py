@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('METRO_HIP_LIB') or os.path.join(HERE, 'libmetro_hip.so')   # override: timing experiments
 
 METRO_MAX_JOINTS = 64
-ABI_VERSION = 2          # include/metro_hip.h METRO_ABI_VERSION
+ABI_VERSION = 3          # include/metro_hip.h METRO_ABI_VERSION
 METRO_PREC_F16, METRO_PREC_F32, METRO_PREC_F64 = 0, 1, 2
 METRO_F16, METRO_F32, METRO_F64 = 0, 1, 2
 PARAM_CONV_W, PARAM_BIAS, PARAM_PRO_SCALE, PARAM_PRO_SHIFT = 0, 1, 2, 3
@@ -40,7 +40,8 @@ class MetroLayerInfo(C.Structure):
                 ('res_stride', C.c_int32), ('res_offset', C.c_int32), ('out_dtype', C.c_int32),
                 ('out_offset', C.c_int64), ('out_bytes_per_image', C.c_int64),
                 ('flops_per_image', C.c_double),
-                ('out2_offset', C.c_int64), ('out2_channels', C.c_int32), ('reserved', C.c_int32)]
+                ('out2_offset', C.c_int64), ('out2_channels', C.c_int32), ('reserved', C.c_int32),
+                ('algo_act_bytes_per_image', C.c_int64), ('algo_param_bytes', C.c_int64)]
 
 
 class MetroConvDesc(C.Structure):

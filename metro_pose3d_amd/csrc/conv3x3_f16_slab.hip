@@ -346,16 +346,8 @@ template <class Cfg>
 static int launch_slab_cfg(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias,
                            half_t* out, int halo, hipStream_t stream) {
     auto kern = conv3x3_f16_slab_kernel<Cfg>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(conv3x3_f16_slab, %d B): %s", Cfg::LDS_BYTES, hipGetErrorString(e));
-            return METRO_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    static PerDeviceInt attr_done;
+    if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES, attr_done, "conv3x3_f16_slab")) return st;
     const int tiles_m = (a.c_out + Cfg::TM - 1) / Cfg::TM;
     const int tiles_n = (a.m_total + Cfg::TN - 1) / Cfg::TN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, a, in, w, bias,
@@ -374,7 +366,7 @@ using Slab64r384b1 = SlabCfg<1, 8, 2, 1, 384, 1>;  // single chunk (c_in == 64),
 using Slab64r320b1 = SlabCfg<1, 8, 2, 1, 320, 1>;
 
 bool conv3x3_slab_supported(const MetroConvDesc& d) {
-    static const int enabled = [] { const char* e = getenv("METRO_CONV_SLAB"); return e ? atoi(e) : 1; }();
+    static const int enabled = tuning_knob("METRO_CONV_SLAB", 1);
     if (!enabled) return false;
     if (!(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.h_in == d.h_out && d.w_in == d.w_out &&
           d.pad_top == d.dilation && d.pad_left == d.dilation && !d.has_prologue && !d.has_residual &&
@@ -403,7 +395,7 @@ int launch_conv3x3_slab(const MetroConvDesc& d, const void* in_, const void* w_,
     if (d.c_out <= 64 || blocks128 < 256) {
         if (d.c_in == 64 && halo <= 32) return launch_slab_cfg<Slab64r320b1>(a, in, w, bias, out, halo, stream);
         if (d.c_in == 64 && halo <= 64) return launch_slab_cfg<Slab64r384b1>(a, in, w, bias, out, halo, stream);
-        static const int t3 = [] { const char* e = getenv("METRO_SLAB_T3"); return e ? atoi(e) : 1; }();
+        static const int t3 = tuning_knob("METRO_SLAB_T3", 1);
         if (t3 && halo <= 32) return launch_slab_cfg<Slab64r320t3>(a, in, w, bias, out, halo, stream);
         if (halo <= 32) return launch_slab_cfg<Slab64r320>(a, in, w, bias, out, halo, stream);
         if (halo <= 64) return launch_slab_cfg<Slab64r384>(a, in, w, bias, out, halo, stream);

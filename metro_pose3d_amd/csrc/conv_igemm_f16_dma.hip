@@ -1,6 +1,7 @@
-// Second-generation fp16 implicit-GEMM convolution: LDS-DMA ring + coalesced epilogue.
+// fp16 implicit-GEMM convolution: LDS-DMA ring + coalesced epilogue.
 //
-// Same contraction, operand roles and swizzled LDS image as conv_igemm_f16.hip, but
+// D[cout][pixel] = sum_{tap,c} W[cout][tap][c] * X[pixel + tap][c]: MFMA A operand = weight rows, B operand = pixels,
+// v_mfma_f32_32x32x16_f16, LDS operand tiles [rows][BK] fp16 with the 16-byte chunk index XOR-swizzled by the row:
 //   * operand tiles go global -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no
 //     ds_write pass): one wave-instruction fills 8 tile rows x 128 B.  The LDS image of an
 //     LDS-DMA is lane-linear, so the XOR chunk swizzle is applied to the per-lane SOURCE address;
@@ -118,7 +119,7 @@ __device__ __forceinline__ void conv_dma_body(
     const int wave_m = wave / Cfg::WAVES_N;
     const int wave_n = wave % Cfg::WAVES_N;
 
-    // XCD-aware (bijective) block -> tile map, as in conv_igemm_f16.hip
+    // XCD-aware (bijective) block -> tile map: the blocks of one XCD share pixel tiles in their L2
     const int nblk = gridDim.x;
     int lid;
     {
@@ -602,10 +603,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_igemm_f16_fuse2_kernel(
     conv_dma_body<Cfg, false, true, true>(a, in, w, bias, nullptr, nullptr, residual, out, 0, 1, nullptr, f2);
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
+static int env_int(const char* name, int dflt) { return tuning_knob(name, dflt); }
 
 static thread_local void* g_out2 = nullptr;   // second output of a fused pair (set by launch_conv_f16_dma)
 
@@ -619,16 +617,8 @@ static int launch_dma_cfg2(const ConvArgs& a, const half_t* in, const half_t* w,
     }
     auto kern = conv_igemm_f16_dma_kernel<Cfg, PROLOGUE, FASTK>;
     constexpr int lds = Cfg::MAIN_BYTES + (PROLOGUE ? Cfg::PRO_BYTES : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(conv_igemm_f16_dma, %d B): %s", lds, hipGetErrorString(e));
-            return METRO_ERR_HIP;
-        }
-        attr_set = true;
-    }
+    static PerDeviceInt attr_done;
+    if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, attr_done, "conv_igemm_f16_dma")) return st;
     const int tiles_m = (a.c_out + Cfg::TM - 1) / Cfg::TM;
     const int tiles_n = (a.m_total + Cfg::TN - 1) / Cfg::TN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::NT), lds, stream, a, in, w, bias, ps, pb,
@@ -671,12 +661,8 @@ static int launch_fuse2(const ConvArgs& a, const half_t* in, const half_t* w, co
     using Cfg = DmaFuse256x64;
     auto kern = conv_igemm_f16_fuse2_kernel<Cfg>;
     constexpr int lds = Cfg::MAIN_BYTES + 64 * Cfg::TM * 2 + 2 * Cfg::TM * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute(conv fuse2): %s", hipGetErrorString(e)); return METRO_ERR_HIP; }
-        attr_set = true;
-    }
+    static PerDeviceInt attr_done;
+    if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, attr_done, "conv_igemm_f16_fuse2")) return st;
     const int tiles_n = (a.m_total + Cfg::TN - 1) / Cfg::TN;
     hipLaunchKernelGGL(kern, dim3(tiles_n), dim3(Cfg::NT), lds, stream, a, in, w, bias, res, out,
                        Fuse2Args{static_cast<const half_t*>(f.w2), f.bias2, static_cast<const half_t*>(f.scale2),
@@ -758,6 +744,16 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
     if (blocks256 >= 256) { METRO_DMA(Dma128x256s3); }
     METRO_DMA(Dma128x128s4);
 #undef METRO_DMA
+}
+
+// fp16 convolution dispatcher (metro_conv_f16 and every plain conv layer of the plan)
+int launch_conv_f16(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* ps,
+                    const void* pb, const void* res, void* out, hipStream_t stream) {
+    if (conv3x3_slab_supported(d)) return launch_conv3x3_slab(d, in, w, bias, out, stream);
+    if (conv_f16_dma_supported(d)) return launch_conv_f16_dma(d, in, w, bias, ps, pb, res, out, stream);
+    set_error("conv_f16: unsupported layer (c_in %d must be a multiple of 8 and <= 2048, in_pix_stride %d of 4 (8 with a "
+              "prologue), c_out %d of 4 (8 with a residual))", d.c_in, d.in_pix_stride, d.c_out);
+    return METRO_ERR_UNSUPPORTED;
 }
 
 }  // namespace metro

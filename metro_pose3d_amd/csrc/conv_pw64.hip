@@ -345,10 +345,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     }
 }
 
-static int pw_env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
+static int pw_env_int(const char* name, int dflt) { return tuning_knob(name, dflt); }
 
 static bool pw_enabled() {
     static const int v = pw_env_int("METRO_PW64", 1);
@@ -381,19 +378,11 @@ static int launch_pw(Pw64Args a, hipStream_t stream) {
     auto kern = conv_pw64_kernel<K, WM, PRO, RES, MODE2, RSUB>;
     constexpr int lds = pw::lds_bytes<K, WM, RES, MODE2>();
     a.n_tiles = (a.m_total + pw::Lay<K, WM>::TN - 1) / pw::Lay<K, WM>::TN;
-    static int grid_cap = 0;
-    if (grid_cap == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute(conv_pw64): %s", hipGetErrorString(e)); return METRO_ERR_HIP; }
-        int dev = 0, cus = 0, occ = 0;
-        METRO_HIP_CHECK(hipGetDevice(&dev));
-        METRO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        METRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, pw::NT, lds));
-        const int cap = pw_env_int("METRO_PW64_BPC", 0);          // blocks per CU (0 = what fits)
-        if (occ < 1) occ = 1;
-        if (cap > 0 && cap < occ) occ = cap;
-        grid_cap = cus * occ;
-    }
+    static PerDeviceInt cap;
+    int grid_cap = 0;
+    if (const int st = ensure_dyn_lds_and_grid_cap(reinterpret_cast<const void*>(kern), pw::NT, lds, cap, "conv_pw64",
+                                                   pw_env_int("METRO_PW64_BPC", 0) /* blocks per CU, 0 = what fits */, &grid_cap))
+        return st;
     const int halves = a.c_out / 256;
     int grid = a.n_tiles * halves < grid_cap ? a.n_tiles * halves : grid_cap;
     grid -= grid % halves;

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/metro_hip.h"
 
@@ -30,6 +31,74 @@ const char* get_error();
             return METRO_ERR_HIP;                                                          \
         }                                                                                  \
     } while (0)
+
+// ---- per-device one-time kernel setup -----------------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the occupancy query act on the CURRENT device's copy of a
+// kernel: a process that drives several GPUs (inference.py caches one Engine per device) must do them once per
+// device, not once per process.  Zero-initialised statics of this type replace `static bool attr_set`.
+constexpr int METRO_MAX_DEVICES = 64;
+struct PerDeviceInt { int v[METRO_MAX_DEVICES]; };
+
+inline int current_device_slot(int* slot) {
+    int dev = 0;
+    const hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= METRO_MAX_DEVICES) {
+        set_error("hipGetDevice: %s (device %d; at most %d devices per process)", hipGetErrorString(e), dev, METRO_MAX_DEVICES);
+        return METRO_ERR_HIP;
+    }
+    *slot = dev;
+    return METRO_OK;
+}
+
+// opts a kernel in to `bytes` of dynamic LDS on the current device (once per device)
+inline int ensure_dyn_lds(const void* kern, int bytes, PerDeviceInt& done, const char* what) {
+    int slot = 0;
+    const int st = current_device_slot(&slot);
+    if (st) return st;
+    if (done.v[slot]) return METRO_OK;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(%s, %d B of LDS, device %d): %s", what, bytes, slot, hipGetErrorString(e));
+        return METRO_ERR_HIP;
+    }
+    done.v[slot] = 1;
+    return METRO_OK;
+}
+
+// same, and returns CUs x resident blocks per CU of the kernel on the current device (persistent kernels' grid cap)
+inline int ensure_dyn_lds_and_grid_cap(const void* kern, int threads, int bytes, PerDeviceInt& cap, const char* what,
+                                       int max_blocks_per_cu, int* grid_cap) {
+    int slot = 0;
+    int st = current_device_slot(&slot);
+    if (st) return st;
+    if (cap.v[slot] == 0) {
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(%s, %d B of LDS, device %d): %s", what, bytes, slot, hipGetErrorString(e));
+            return METRO_ERR_HIP;
+        }
+        int cus = 0, occ = 0;
+        METRO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, slot));
+        METRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, bytes));
+        if (occ < 1) occ = 1;
+        if (max_blocks_per_cu > 0 && occ > max_blocks_per_cu) occ = max_blocks_per_cu;
+        cap.v[slot] = cus * occ;
+    }
+    *grid_cap = cap.v[slot];
+    return METRO_OK;
+}
+
+// Tuning knobs: compile-time constants in the product build.  A build with -DMETRO_TUNING_KNOBS (tools/
+// build_dbg_variants.sh, A/B timing runs) reads them from the environment instead; the product never calls getenv.
+inline int tuning_knob(const char* name, int dflt) {
+#ifdef METRO_TUNING_KNOBS
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 inline int launch_status(const char* what) {
     hipError_t e = hipGetLastError();
@@ -89,11 +158,11 @@ inline ConvArgs make_conv_args(const MetroConvDesc& d) {
 int validate_conv_desc(const MetroConvDesc* d);
 
 // kernel launchers implemented in the .hip files
+// fp16 convolution dispatcher: tap-reuse slab kernel for 3x3 stride-1 layers, the LDS-DMA ring kernel otherwise
 int launch_conv_f16(const MetroConvDesc& d, const void* in, const void* w, const float* bias,
                     const void* pro_scale, const void* pro_shift, const void* residual, void* out,
                     hipStream_t stream);
-// second-generation kernel (LDS-DMA ring, coalesced epilogue); falls back to launch_conv_f16's
-// register-staged kernel when the layer is not supported (the 4-channel stem image)
+// LDS-DMA ring kernel (coalesced epilogue)
 bool conv_f16_dma_supported(const MetroConvDesc& d);
 int launch_conv_f16_dma(const MetroConvDesc& d, const void* in, const void* w, const float* bias,
                         const void* pro_scale, const void* pro_shift, const void* residual, void* out,

@@ -5,7 +5,7 @@
 // src/model/architectures.py:24-35 -> src/model/resnet_v2.py:142-312 ->
 // src/model/resnet_utils.py:263-350) as a flat list of kernel launches over a pre-planned
 // workspace.  The test-side oracle (oracle/spec.py) restates the same control flow
-// independently in Python; tests/test_plan_vs_oracle.py compares the two layer by layer.
+// independently in Python; tests/test_abi_and_plan.py compares the two layer by layer.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -185,8 +185,8 @@ struct Builder {
     // unit read the same pre-activated tensor: one launch over concatenated weight rows
     // (reference resnet_v2.py:122-128).  Parameter tensors keep their own names and are laid out
     // back to back so the kernel sees one [c_sc + cb][c_in] matrix.
-    void add_shortcut_conv1_pair(const std::string& un, const std::string& sc, int in_slot, int side, int c_in,
-                                 int c_sc, int cb, int adt) {
+    int add_shortcut_conv1_pair(const std::string& un, const std::string& sc, int in_slot, int side, int c_in,
+                                int c_sc, int cb, int adt) {
         Layer L;
         memset(&L, 0, sizeof(L));
         L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
@@ -207,7 +207,8 @@ struct Builder {
         // contiguity (sizes are multiples of the 256-byte blob alignment for c_sc % 256 == 0, c_in % 64 == 0)
         if (p->params[w2].offset != p->params[L.p_w].offset + p->params[L.p_w].bytes ||
             p->params[b2].offset != p->params[L.p_bias].offset + p->params[L.p_bias].bytes) {
-            set_error("internal: fused pair parameters are not contiguous");
+            set_error("internal: fused pair parameters of %s are not contiguous in the blob", un.c_str());
+            return METRO_ERR_STATE;       // the kernel reads conv1's rows at w + c_sc * c_in: never launch on a broken layout
         }
         L.p_scale = add_param(un + "/shortcut/pro_scale", METRO_PARAM_PRO_SCALE, "", pre, METRO_F16, c_in, 1, 1, 1, 1, 1);
         L.p_shift = add_param(un + "/shortcut/pro_shift", METRO_PARAM_PRO_SHIFT, "", pre, METRO_F16, c_in, 1, 1, 1, 1, 1);
@@ -218,6 +219,7 @@ struct Builder {
         fill_info(L, un + "/shortcut+conv1", 2.0 * side * side * (double)(c_sc + cb) * c_in);
         L.info.c_out = c_sc;      // the primary output tensor (S_SC) has c_sc channels
         p->layers.push_back(L);
+        return METRO_OK;
     }
 
     // Appends conv1 of the NEXT unit (1x1, cb outputs, folded BN + ReLU, pre-activation prologue of that
@@ -406,7 +408,8 @@ int build_plan(MetroPlan* p) {
             if (conv1_done) {
                 conv1_done = false;       // S_T1 already holds relu(bn(conv1(preact(x))))
             } else if (fuse_pair) {
-                B.add_shortcut_conv1_pair(un, sc, cur, cur_side, cur_c, cout, cb, adt);
+                const int pst = B.add_shortcut_conv1_pair(un, sc, cur, cur_side, cur_c, cout, cb, adt);
+                if (pst != METRO_OK) return pst;
             } else {
                 if (project) {
                     // conv1x1(shift(preact), stride s) + bias: input pixel = shift + s*ho
@@ -481,6 +484,23 @@ int build_plan(MetroPlan* p) {
         const bool two = L.kind == LK_CONV && (L.split > 0 || L.f2_w >= 0);
         L.info.out2_offset = two ? p->slot_offset[L.out2_slot] : -1;
         L.info.out2_channels = two ? (L.split > 0 ? L.c_out2 : L.f2_c2) : 0;
+        // algorithmic bytes: every tensor the launch touches, once
+        const int64_t in_es = L.in_slot == S_IMAGES ? 4 : (L.kind == LK_SOFTARGMAX ? (sp.precision == METRO_PREC_F64 ? 8 : 4)
+                                                           : (L.kind == LK_CONV && !fast ? aes : (L.kind == LK_CONV ? 2 : aes)));
+        int64_t act = 0;
+        if (L.in_slot == S_IMAGES) act += (int64_t)sp.proc_side * sp.proc_side * 3 * 4;
+        else if (L.kind == LK_CONV && L.cd.in_pix_stride != L.cd.c_in) act += (int64_t)L.cd.h_in * L.cd.w_in * L.cd.in_pix_stride * in_es;
+        else act += (int64_t)L.cd.h_in * L.cd.w_in * L.cd.c_in * in_es;
+        if (L.kind == LK_SOFTARGMAX) act += (int64_t)sp.n_joints_out * 3 * 4;
+        else act += L.info.out_bytes_per_image;
+        if (two) act += (int64_t)L.cd.h_out * L.cd.w_out * L.info.out2_channels * es;
+        if (L.kind == LK_CONV && L.cd.has_residual) act += (int64_t)L.cd.h_out * L.cd.w_out * L.cd.c_out * es;
+        L.info.algo_act_bytes_per_image = act;
+        int64_t pb = 0;
+        for (int idx : {L.p_w, L.p_bias, L.p_scale, L.p_shift, L.f2_w, L.f2_bias, L.f2_scale, L.f2_shift})
+            if (idx >= 0) pb += p->params[idx].bytes;
+        if (L.split > 0) pb += p->params[L.p_w + 1].bytes + p->params[L.p_bias + 1].bytes;   // conv1 rows of a fused pair
+        L.info.algo_param_bytes = pb;
     }
     return METRO_OK;
 }
@@ -646,6 +666,10 @@ int metro_plan_bind_params(MetroPlan* plan, const void* d_param_blob) {
     METRO_CHECK_ARG(plan && d_param_blob, "metro_plan_bind_params: NULL argument");
     METRO_CHECK_ARG(((uintptr_t)d_param_blob & 255) == 0, "parameter blob must be 256-byte aligned");
     plan->d_params = static_cast<const char*>(d_param_blob);
+    // captured forwards bake the OLD blob's pointers into their kernel arguments: drop them
+    for (GraphEntry& g : plan->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    plan->graphs.clear();
     return METRO_OK;
 }
 

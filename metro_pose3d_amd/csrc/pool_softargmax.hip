@@ -366,13 +366,8 @@ static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void
     const size_t lds = (size_t)ppb * C * 4 * sizeof(AccT);
     auto kern = softargmax_partial_kernel<AccT, LogitT>;
     if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { set_error("hipFuncSetAttribute(softargmax): %s", hipGetErrorString(e)); return METRO_ERR_HIP; }
-            attr_set = true;
-        }
+        static PerDeviceInt attr_done;
+        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done, "softargmax_partial")) return st;
     }
     hipLaunchKernelGGL(kern, dim3(slabs, a.n), dim3(SA_NT), lds, stream, static_cast<const LogitT*>(logits),
                        static_cast<AccT*>(partials), a.side, a.depth, a.n_joints_head, slabs);

@@ -328,10 +328,7 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
     }
 }
 
-static int sp_env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
+static int sp_env_int(const char* name, int dflt) { return tuning_knob(name, dflt); }
 
 bool stem_pool_f16_supported(int side, int base_width) {
     static const int enabled = sp_env_int("METRO_STEM_POOL", 1);
@@ -382,19 +379,10 @@ template <int NSPLIT, bool RAW>
 static int launch_sp(const StemPoolArgs& a, hipStream_t stream) {
     auto kern = stem_pool_f16_kernel<NSPLIT, RAW>;
     constexpr int NT = 64 * sp::MG * NSPLIT;
-    static int grid_cap = 0;
-    if (grid_cap == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, sp::LDS_BYTES);
-        if (e != hipSuccess) { set_error("hipFuncSetAttribute(stem_pool): %s", hipGetErrorString(e)); return METRO_ERR_HIP; }
-        int dev = 0, cus = 0, occ = 0;
-        METRO_HIP_CHECK(hipGetDevice(&dev));
-        METRO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        METRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, NT, sp::LDS_BYTES));
-        if (occ < 1) occ = 1;
-        grid_cap = cus * occ;
-        if (sp_env_int("METRO_DEBUG", 0)) fprintf(stderr, "stem_pool_f16: %d CUs x %d blocks\n", cus, occ);
-    }
+    static PerDeviceInt cap;
+    int grid_cap = 0;
+    if (const int st = ensure_dyn_lds_and_grid_cap(reinterpret_cast<const void*>(kern), NT, sp::LDS_BYTES, cap, "stem_pool_f16", 0, &grid_cap))
+        return st;
     const int grid = a.n_patches < grid_cap ? a.n_patches : grid_cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), sp::LDS_BYTES, stream, a);
     return launch_status("stem_pool_f16");

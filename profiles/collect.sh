@@ -8,10 +8,10 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/trace -o $tag -- python bench.py --steps 10 --warmup 3 --cpu-seconds 0 > $out/bench_under_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/trace -o $tag -- python bench.py --steps 10 --warmup 3 --cpu-seconds 0 --no-extras > $out/bench_under_trace.log 2>&1
 python profiles/summarize_rocprof.py $(find $out/trace -name "*.db" | head -1) $out/${tag}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc/$c -o $tag -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 > $out/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc/$c -o $tag -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extras > $out/pmc_$c.log 2>&1
 done
 python profiles/pmc_table.py $out/pmc 1 > $out/${tag}_pmc_layers.tsv
 python profiles/pmc_traffic.py $out/${tag}_pmc_layers.tsv $tag > $out/${tag}_pmc_traffic.json

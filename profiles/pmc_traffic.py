@@ -7,10 +7,19 @@ gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per
 reads, so bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
 import csv
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def main(tsv, tag):
+    from bench import kernels_sha16
+    from metro_pose3d_amd import ModelSpec, _lib
+    from metro_pose3d_amd.engine import Engine
+    infos = Engine(ModelSpec(50, 16, 'h36m'), None, 'f16', 64).layer_infos()
+    algo = sum(li.algo_act_bytes_per_image * 64 + li.algo_param_bytes for li in infos if li.kind == _lib.LAYER_CONV)
     rows = list(csv.DictReader(open(tsv), delimiter='\t'))
     conv = [r for r in rows if r['layer'].startswith(('conv1', 'block', 'logits'))]
     f = sum(float(r['FETCH_SIZE']) for r in conv)
@@ -23,13 +32,15 @@ def main(tsv, tag):
         'correction': 'FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads on gfx950 (MI355X_MICROARCH.md, '
                       'HBM section): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024',
         'batch': 64,
+        'kernels_sha16': kernels_sha16(),
         'conv_launches': len(conv),
         'conv_fetch_size_kb_raw': f,
         'conv_write_size_kb': w,
         'conv_hbm_bytes_per_forward': (2 * f + w) * 1024,
         'conv_hbm_bytes_per_launch_avg': (2 * f + w) * 1024 / max(len(conv), 1),
         'all_kernels_hbm_bytes_per_forward': (2 * fa + wa) * 1024,
-        'algorithmic_min_bytes_per_forward_fp16_every_layer_roundtrip': None,
+        'algorithmic_min_bytes_per_forward_this_launch_set': int(algo),
+        'measured_over_algorithmic': round((2 * f + w) * 1024 / algo, 3),
     }, indent=1))
 
 

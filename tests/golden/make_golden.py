@@ -3,6 +3,7 @@
 
     python tests/golden/make_golden.py --calibrate   # prints the LOGIT_GAIN table for synth.py
     python tests/golden/make_golden.py               # writes golden_poses_v1.npz
+    python tests/golden/make_golden.py --f16         # writes golden_f16emu_v1.npz (fp16-faithful oracle, oracle/f16emu.py)
 
 The reference itself (TensorFlow 1.13 + a frozen .pb) cannot run here, so these vectors pin the
 ORACLE (and through it the HIP path), not TensorFlow: "parity unpinned", see oracle/__init__.py.
@@ -25,10 +26,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from metro_pose3d_amd import ModelSpec, synth  # noqa: E402
+from oracle import f16emu  # noqa: E402
 from oracle import forward as OF  # noqa: E402
 from oracle.spec import OracleSpec, head_joint_info  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden_poses_v1.npz')
+OUT_F16 = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden_f16emu_v1.npz')
 
 # (case name, ModelSpec, batch)
 CASES = [
@@ -89,13 +92,37 @@ def calibrate():
     return table
 
 
+def make_f16():
+    """Poses of the fp16 arithmetic model (one rounding per stored tensor) for the same seeded cases, plus probes of
+    its fp16 tensors: pins oracle/f16emu.py, which the GPU tests hold the benchmarked f16 mode to."""
+    out = {}
+    for name, spec, n in CASES:
+        params = synth.make_params(spec.arch, spec.n_head_channels, spec.base_width, seed=0, logit_gain=gain_for(spec))
+        images = synth.make_images(n, spec.proc_side)
+        col = {}
+        with torch.no_grad():
+            poses = f16emu.forward(ospec(spec), params, images, col).numpy()
+        out[name + '/poses_f16emu'] = poses
+        for key in ('pool1', 'block1/unit_1', 'block2/unit_4', 'block4/unit_3', 'logits'):
+            flat = col[key].reshape(-1)
+            idx = np.linspace(0, flat.numel() - 1, 16).astype(np.int64)
+            out[f'{name}/probe16/{key}'] = flat[idx].numpy()
+        print(f'{name}: f16emu poses {poses.shape}', flush=True)
+    np.savez_compressed(OUT_F16, **out)
+    print(f'wrote {OUT_F16} ({os.path.getsize(OUT_F16) / 1024:.1f} KiB)')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--calibrate', action='store_true')
+    ap.add_argument('--f16', action='store_true')
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 1)
     if args.calibrate:
         calibrate()
+        return
+    if args.f16:
+        make_f16()
         return
     out = {}
     meta = {}

@@ -1,0 +1,203 @@
+"""The BENCHMARKED fp16 path, layer by layer at full width, against the fp16-faithful oracle (`-m gpu`).
+
+oracle/f16emu.py restates the graph with one fp16 rounding per stored tensor (the arithmetic the f16 mode of the
+HIP path implements; see its header for how that relates to the reference's fp16 graph).  What is left between
+the two is the accumulation order inside a convolution (fp32 MFMA vs exact): one-ulp flips of fp16 results.
+
+Two comparisons, over EVERY launch of the plan and both outputs of fused launches:
+
+  * per launch ("teacher forced"): the oracle function of that tensor is fed the HIP path's OWN input tensors, so
+    nothing propagates and the bar is a rounding flip: every element within ONE fp16 ulp of its own magnitude
+    (floored at 1/64 of the layer maximum, where the absolute fp32 accumulation noise of a dot product lives) and
+    >= 99 % of the elements bit-identical.  A wrong tile, channel, tap, pad or residual cannot pass this.
+  * whole graph: one-ulp flips of a large activation move every output of that pixel by w * ulp, so two fp16
+    chains decorrelate at the ulp level with depth (measured: 99.96 % identical after the stem, ~20-60 % in
+    block4, poses 0.3-2 mm apart -- the same distance either chain has to exact math).  The layers are held to
+    8 ulps of the layer maximum end to end; the POSES must be as close to the exact (fp64) oracle as the fp16
+    oracle's own poses are (x POSE_RATIO, max and mean): fp16 storage costs 1.5-3.5 mm on these nets, and the HIP
+    path may not cost more.  The soft-argmax launch is held to 1e-3 mm against exact math on its own fp32 logits.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from metro_pose3d_amd import ModelSpec, _lib, synth
+from metro_pose3d_amd.engine import Engine
+from oracle import f16emu
+from oracle import forward as OF
+from oracle.forward import coords01_to_output, soft_argmax01
+from oracle.spec import head_joint_info, schedule
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+POSE_RATIO = 1.5               # whole graph: |hip - exact| <= POSE_RATIO * |fp16 oracle - exact| (max and mean)
+SOFTARGMAX_TOL_MM = 1e-3       # soft-argmax kernel (fp32, fast exp) vs exact math on the same fp32 logits
+CHAIN_ULPS_OF_MAX = 8.0        # whole-graph layer tensors, in fp16 ulps of the layer maximum
+MIN_IDENTICAL = 0.995          # same-input comparison: fraction of bit-identical elements per tensor
+
+
+def ospec_joints(ospec):
+    return head_joint_info(ospec.dataset).n_joints
+# (spec, crops): the five BASELINE.json configs at full base width (+ stride 8 RN50, the non-centered variant)
+CASES = [(ModelSpec(50, 32, 'h36m'), 2), (ModelSpec(50, 16, 'h36m'), 3), (ModelSpec(50, 16, 'many19'), 1),
+         (ModelSpec(101, 8, 'many19'), 1), (ModelSpec(50, 4, 'h36m'), 1), (ModelSpec(50, 8, 'merged'), 1),
+         (ModelSpec(50, 16, 'h36m', centered_stride=False), 1)]
+_id = lambda c: f'rn{c[0].arch}-s{c[0].stride}-{c[0].dataset}-n{c[1]}' + ('' if c[0].centered_stride else '-nc')
+
+
+def ulp16(v):
+    """Spacing of fp16 numbers at magnitude |v| (normal range; 2^-24 below it)."""
+    v = np.maximum(np.abs(v), 2.0 ** -14)
+    return 2.0 ** (np.floor(np.log2(v)) - 10)
+
+
+def layer_keys(name):
+    """plan layer name -> (oracle key of the primary output, oracle key of the second output or None)."""
+    if name == 'conv1+pool1':
+        return 'pool1', None
+    if name in ('conv1', 'pool1', 'logits'):
+        return name, None
+    if name.endswith('/shortcut+conv1'):
+        unit = name[:-len('/shortcut+conv1')]
+        return unit + '/shortcut', unit + '/conv1'
+    if '/conv3+' in name:
+        unit, nxt = name.split('/conv3+')
+        return unit, f'{unit.split("/")[0]}/{nxt}'
+    if name.endswith('/conv3'):
+        return name[:-len('/conv3')], None
+    if name.endswith(('/conv1', '/conv2', '/shortcut')):
+        return name, None
+    return None, None
+
+
+def compare_fp16(got, ref, what, chained=False, addend=None):
+    """chained=False: got and ref were computed from the same inputs; chained=True: whole-graph comparison.
+    addend: for a residual sum fp16(shortcut + fp16(conv)), the shortcut -- the flip happens at the magnitude of the
+    conv term (<= |sum| + |shortcut|), which cancellation can leave far above the sum's own."""
+    ref_max = float(np.abs(ref).max())
+    err = np.abs(got - ref)
+    worst = float(err.max()) / float(ulp16(ref_max))
+    # elements far below the layer maximum (ReLU zeros, cancellations) carry the ABSOLUTE fp32-accumulation noise of
+    # their dot product, not a relative one: their yardstick is floored at 1/64 of the maximum
+    mag = np.maximum(np.maximum(np.abs(ref), np.abs(got)), ref_max / 64)
+    if addend is not None:
+        mag = 2.0 * np.maximum(mag, np.abs(addend))
+    own = err / ulp16(mag)
+    own_max = float(own.max())
+    frac_equal = float((got == ref).mean())
+    rep = os.environ.get('METRO_F16_REPORT')
+    if rep:
+        with open(rep, 'a') as f:
+            f.write(f'{what}\t{int(chained)}\t{ref_max:.4g}\t{worst:.3f}\t{frac_equal:.5f}\t{own_max:.2f}\n')
+        return worst, frac_equal
+    if chained:
+        assert worst <= CHAIN_ULPS_OF_MAX, f'{what}: {worst:.2f} ulps of the layer maximum {ref_max:.4g} (whole graph)'
+    else:
+        assert own_max <= 1.0, f'{what}: an element is {own_max:.2f} ulps of its own magnitude off (same inputs)'
+        assert frac_equal >= MIN_IDENTICAL, f'{what}: only {frac_equal:.5f} of the elements bit-identical (same inputs)'
+    return worst, frac_equal
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).numpy()
+
+
+@pytest.mark.parametrize('case', CASES, ids=_id)
+def test_f16_mode_layerwise_against_fp16_oracle(cuda, case):
+    spec, n = case
+    params = synth.make_params(spec.arch, spec.n_head_channels, spec.base_width, seed=0,
+                               logit_gain=synth.logit_gain_for(spec.arch, spec.stride))
+    images = synth.make_images(n, spec.proc_side, seed=4321)
+    ospec = H.oracle_spec(spec)
+    col = {}
+    want = f16emu.forward(ospec, params, images, col).numpy()              # whole graph, fp16 model
+    exact = OF.forward(ospec, params, images, torch.float64).numpy()       # whole graph, exact
+    root = f'MainPart/{ospec.arch_name}'
+    units = {u.name: u for u in schedule(ospec)}
+    order = list(units)
+    x = torch.from_numpy(images).to(cuda)
+    eng = Engine(spec, params, 'f16', max_batch=n, device=cuda)
+    hip = {}                                                               # oracle key -> the HIP path's tensor (NCHW fp64)
+
+    def fetch(i, second=False):
+        return eng.forward_upto(x, i, second=second).cpu().double().permute(0, 3, 1, 2).contiguous()
+
+    def unit_input(uname):
+        k = order.index(uname)
+        return hip['pool1'] if k == 0 else hip[order[k - 1]]
+
+    checked = 0
+    for i, li in enumerate(eng.layer_infos()):
+        name = li.name.decode()
+        if li.kind == _lib.LAYER_SOFTARGMAX:
+            continue
+        k1, k2 = layer_keys(name)
+        assert k1 is not None and k1 in col, f'layer {name!r} has no oracle counterpart'
+        got = fetch(i)
+        hip[k1] = got
+        # ---- the oracle function of this tensor on the HIP path's own inputs -------------------------
+        ref2 = addend = None
+        if k1 == 'pool1':
+            ref = f16emu.stem_pool(params, root, images)
+        elif k1 == 'logits':
+            ref = f16emu.head_logits(hip[order[-1]], params, root)
+        else:
+            uname = '/'.join(k1.split('/')[:2])
+            unit, pre = units[uname], f'{root}/{uname}/bottleneck_v2'
+            kind = k1[len(uname):]
+            if kind == '/shortcut':
+                ref = f16emu.unit_shortcut(unit_input(uname), params, pre, unit)
+            elif kind == '/conv1':
+                ref = f16emu.unit_conv1(unit_input(uname), params, pre)
+            elif kind == '/conv2':
+                ref = f16emu.unit_conv2(hip[uname + '/conv1'], params, pre, unit)
+            else:
+                assert kind == '', k1
+                sc = hip[uname + '/shortcut'] if unit.c_in != unit.c_out else \
+                    f16emu.unit_shortcut(unit_input(uname), params, pre, unit)
+                ref = f16emu.unit_conv3_add(hip[uname + '/conv2'], sc, params, pre)
+                addend = nhwc(sc)
+            if k2 is not None:
+                u2 = '/'.join(k2.split('/')[:2])
+                src = got if u2 != uname else unit_input(uname)             # next unit's conv1 reads THIS launch's output
+                ref2 = f16emu.unit_conv1(src, params, f'{root}/{u2}/bottleneck_v2')
+        assert tuple(got.shape) == tuple(ref.shape), (name, got.shape, ref.shape)
+        if li.out_dtype == _lib.METRO_F16:
+            compare_fp16(nhwc(got), nhwc(ref), name, addend=addend)
+            compare_fp16(nhwc(got), nhwc(col[k1]), name, chained=True)
+        else:                                                               # fp32 logits: fp32 accumulation noise only
+            rel = float((got - ref).abs().max() / ref.abs().max())
+            assert rel <= 2e-6, (name, rel)
+            rel_chain = float((got - col[k1]).abs().max() / col[k1].abs().max())
+            assert rel_chain <= 1e-2, (name, rel_chain)
+        checked += 1
+        if li.out2_offset >= 0:
+            assert k2 is not None and k2 in col and ref2 is not None, f'second output of {name!r} has no oracle counterpart'
+            got2 = fetch(i, second=True)
+            hip[k2] = got2
+            compare_fp16(nhwc(got2), nhwc(ref2), name + ' (second output)')
+            compare_fp16(nhwc(got2), nhwc(col[k2]), name + ' (second output)', chained=True)
+            checked += 1
+    assert checked >= len(eng.layer_infos()) - 1
+    # ---- soft-argmax on the HIP path's own logits, then the whole graph ---------------------------------
+    poses = eng.forward(x).cpu().numpy()
+    _, c01 = soft_argmax01(hip['logits'], ospec_joints(ospec), ospec.depth)
+    d_sa = float(np.abs(poses - coords01_to_output(ospec, c01).numpy()).max())
+    d_emu = float(np.abs(poses - want).max())
+    d_exact = float(np.abs(poses - exact).max())
+    emu_exact = float(np.abs(want - exact).max())
+    print(f'\n[{_id(case)}] {checked} tensors; poses: |hip - softargmax64(hip logits)| {d_sa:.2e} mm, |hip - f16emu| {d_emu:.4f} mm, '
+          f'|hip - fp64| {d_exact:.3f} mm, |f16emu - fp64| {emu_exact:.3f} mm')
+    rep = os.environ.get('METRO_F16_REPORT')
+    if rep:
+        with open(rep, 'a') as f:
+            f.write(f'POSES {_id(case)}\t{d_sa:.3e}\t{d_emu:.4f}\t{d_exact:.3f}\t{emu_exact:.3f}\n')
+        return
+    assert d_sa <= SOFTARGMAX_TOL_MM, d_sa
+    # two fp16 realisations of one graph are two samples of the same rounding noise (|hip - f16emu| is 0.3-2 mm here,
+    # like either one's distance to exact math): the HIP path must be as ACCURATE as the fp16 model, not equal to it
+    assert d_exact <= POSE_RATIO * emu_exact, (d_exact, emu_exact)
+    assert np.abs(poses - exact).mean() <= POSE_RATIO * np.abs(want - exact).mean()

@@ -3,8 +3,9 @@
 Bars (BASELINE.json north star): parity mode (precision='f64': fp32 images/weights in, fp32
 poses out, fp64 arithmetic and storage inside) within 1e-3 mm of the oracle; the fp32-storage
 mode sits at the fp32 rounding floor (~1e-3 mm) and is held to 5e-3 mm; fp16
-mode is the reference's own default compute dtype (options.py:73) and is held to the tolerance
-its 11-bit activations allow, measured against the same oracle.
+mode is the reference's own default compute dtype (options.py:73): every launch is held to a
+rounding flip against the fp16-faithful oracle in tests/test_f16_layerwise.py, and its poses to
+the accuracy of that fp16 model of the graph.
 """
 import numpy as np
 import pytest
@@ -146,9 +147,12 @@ def test_full_rn50_s16_all_modes(cuda):
     assert np.abs(got32 - ref).max() <= TOL_F32_STORAGE_MM, np.abs(got32 - ref).max()
     got16 = Engine(spec, params, 'f16', max_batch=2, device=cuda).forward(x).cpu().numpy()
     assert np.isfinite(got16).all()
-    # fp16 activations (rel 5e-4 per layer over 50+ layers) -> logits off by ~1e-2 -> a few mm
-    assert np.abs(got16 - ref).max() <= 25.0, np.abs(got16 - ref).max()
-    assert np.abs(got16 - ref).mean() <= 5.0
+    # fp16 activations (rel 5e-4 per layer over 50+ layers) cost a few mm; the f16 mode must be as accurate as the
+    # one-rounding-per-tensor fp16 model of the graph (per launch: tests/test_f16_layerwise.py)
+    from oracle import f16emu
+    emu = f16emu.forward(H.oracle_spec(spec), params, images).numpy()
+    e16, eemu = np.abs(got16 - ref), np.abs(emu - ref)
+    assert e16.max() <= 1.5 * eemu.max() and e16.mean() <= 1.5 * eemu.mean(), (e16.max(), eemu.max(), e16.mean(), eemu.mean())
 
 
 def test_batch_independence_bit_exact(cuda):
@@ -176,6 +180,22 @@ def test_batch_independence_full_width_persistent_kernels(cuda):
     assert torch.isfinite(whole).all()
     parts = torch.cat([eng.forward(x[:1]).clone(), eng.forward(x[1:6]).clone(), eng.forward(x[6:]).clone()])
     assert torch.equal(whole, parts)
+
+
+def test_two_devices_in_one_process(cuda):
+    """One process may drive several GPUs (inference._engine_for caches one Engine per device): the per-kernel LDS
+    opt-in and the persistent kernels' grid caps are per DEVICE (metro_common.h: PerDeviceInt), so the second device
+    runs the > 64 KiB-LDS kernels too.  Needs two visible GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two visible GPUs')
+    spec = ModelSpec(50, 16, 'h36m')
+    params, images = _setup(spec, 2, gain=synth.logit_gain_for(50, 16))
+    outs = []
+    for d in (0, 1):
+        dev = torch.device('cuda', d)
+        with torch.cuda.device(dev):
+            outs.append(Engine(spec, params, 'f16', max_batch=2, device=dev).forward(torch.from_numpy(images).to(dev)).cpu())
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
 
 
 def test_estimate_pose_boundary(cuda, tmp_path):
