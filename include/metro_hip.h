@@ -188,6 +188,14 @@ int  metro_conv_f16_pair(const MetroConvDesc* d, const void* d_in, const void* d
 int  metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                          const void* d_residual, void* d_out, const void* d_w2, const float* d_bias2,
                          const void* d_scale2, const void* d_shift2, void* d_out2, int32_t c2, void* stream);
+/* The same contract as metro_conv_f16 / metro_conv_f16_pair on the 256 x 256 x 64 GEMM kernel with the 8-phase
+ * two-wave-group schedule (conv_gemm8p.hip), which metro_forward picks for the deep-K 1x1 layers with at least one
+ * tile per CU (conv1, projection shortcut, shortcut+conv1 pair of blocks 3-4: reference resnet_v2.py:122-128).
+ * 1x1, stride 1, c_in % 128 == 0, c_out % 256 == 0, n*h*w % 256 == 0.  split > 0: fused pair (rows [0,split) ->
+ * d_out, rows [split, c_out) with ReLU -> d_out2, c_out - split == 256); split == 0: plain layer, d_out2 ignored. */
+int  metro_conv_f16_gemm8p(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
+                           const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
+                           int32_t split, void* d_out2, void* stream);
 /* Stem 7x7/2 convolution (+bias) and zero-padded 3x3/2 max-pool in one launch (reference resnet_v2.py:219-224,
  * resnet_utils.py:138-185).  d_prepped = metro_prep_input_f16 output [n,side+6,side+8,4] fp16, d_w packed
  * [64][7][8][4] fp16, d_out fp16 [n,side/4,side/4,64].  side % 32 == 0. */

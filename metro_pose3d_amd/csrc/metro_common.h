@@ -168,6 +168,11 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in, const void* w, c
                         const void* pro_scale, const void* pro_shift, const void* residual, void* out,
                         hipStream_t stream, const ConvSplit* split = nullptr, const ConvFuse2* fuse2 = nullptr);
 bool conv_f16_fuse2_supported(const MetroConvDesc& d, int c2);
+// 256 x 256 x 64 GEMM with the 8-phase two-wave-group schedule (conv_gemm8p.hip): deep-K 1x1 layers with >= 256 tiles
+bool conv_gemm8p_shape_ok(const MetroConvDesc& d, const ConvSplit* split);      // what the kernel can run
+bool conv_gemm8p_supported(const MetroConvDesc& d, const ConvSplit* split);     // ... and when the planner prefers it
+int launch_conv_gemm8p(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* pro_scale,
+                       const void* pro_shift, const void* residual, void* out, hipStream_t stream, const ConvSplit* split);
 // persistent pipelined kernel for block1's 64-channel 1x1 convolutions (conv_pw64.hip); mode: 0 plain,
 // 1 projection shortcut + conv1 pair (c_out = 256 + 64 concatenated rows), 2 conv3 + the next unit's conv1
 bool conv_pw64_supported(const MetroConvDesc& d, int mode);

@@ -365,3 +365,78 @@ def test_error_reporting(lib):
     st = lib.metro_conv_f16(C.byref(d), C.c_void_p(256), C.c_void_p(256), C.c_void_p(256), None, None, None,
                             C.c_void_p(256), None)
     assert st == -1 and b'multiple of 8' in lib.metro_last_error()
+
+
+# ---- 8-phase 256 x 256 GEMM kernel (conv_gemm8p.hip) ---------------------------------------------------------------
+# (name, images of 16x16, c_in, c_out, variant)
+G8_CASES = [('k128', 2, 128, 256, 'plain'), ('k256_relu', 3, 256, 512, 'relu'), ('k512_pro', 2, 512, 256, 'prologue'),
+            ('k1024_pro_relu', 5, 1024, 512, 'prologue+relu'), ('k512_res', 3, 512, 768, 'residual'),
+            ('k2048_pro', 2, 2048, 256, 'prologue'), ('pair_k512', 3, 512, 1280, 'pair'), ('pair_k256', 2, 256, 512, 'pair')]
+
+
+@pytest.mark.parametrize('case', G8_CASES, ids=[c[0] for c in G8_CASES])
+def test_conv_gemm8p(lib, cuda, case):
+    """Every element against fp64 on the same fp16 operands: 2e-3 of the layer maximum (fp16 output rounding), for the
+    plain / ReLU / pre-activation / shortcut epilogues and the fused shortcut+conv1 pair routing (reference
+    resnet_v2.py:119-138), K from 2 to 32 tiles, several tiles per launch; repeated launches are bit-identical (the
+    ring is ordered by hand-counted s_waitcnt vmcnt(4) + barriers between two wave groups a barrier apart)."""
+    name, n, c_in, c_out, variant = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    x, w, b = _mk(rng, n, 16, c_in, c_out, 1)
+    x16, w16 = x.astype(np.float16), w.astype(np.float16)
+    pro = res = None
+    if 'prologue' in variant or variant == 'pair':
+        pro = (rng.uniform(0.5, 1.5, c_in).astype(np.float16), (rng.standard_normal(c_in) * 0.3).astype(np.float16))
+    if variant == 'residual':
+        res = rng.standard_normal((n, 16, 16, c_out)).astype(np.float16)
+    relu = 'relu' in variant
+    split = c_out - 256 if variant == 'pair' else 0
+    d = H.conv_desc(n, 16, c_in, 16, c_out, 1, prologue=pro is not None, relu=relu, residual=res is not None, res_h=16)
+    tx = torch.from_numpy(x16).to(cuda)
+    tw = torch.from_numpy(np.ascontiguousarray(w16.reshape(c_out, c_in))).to(cuda)
+    tb = torch.from_numpy(b).to(cuda)
+    ts = torch.from_numpy(pro[0]).to(cuda) if pro else None
+    tsh = torch.from_numpy(pro[1]).to(cuda) if pro else None
+    tr = torch.from_numpy(res).to(cuda) if res is not None else None
+    c1 = split if split else c_out
+    out = torch.full((n, 16, 16, c1), float('nan'), dtype=torch.float16, device=cuda)
+    out2 = torch.full((n, 16, 16, 256), float('nan'), dtype=torch.float16, device=cuda) if split else None
+
+    def run():
+        check(lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(tx), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr),
+                                        H.ptr(out), split, H.ptr(out2), C.c_void_p(0)), 'metro_conv_f16_gemm8p')
+        torch.cuda.synchronize()
+        return out.clone(), (out2.clone() if split else None)
+
+    g1, g2 = run()
+    xin = x16.astype(np.float64)
+    if pro is not None:       # fp16 FMA + ReLU, one rounding (the kernel's v_pk_fma_f16)
+        xin = np.maximum((xin * pro[0].astype(np.float64) + pro[1].astype(np.float64)).astype(np.float16).astype(np.float64), 0)
+    y = xin.reshape(-1, c_in) @ w16.reshape(c_out, c_in).astype(np.float64).T + b.astype(np.float64)
+    y = y.reshape(n, 16, 16, c_out)
+    if split:
+        want1, want2 = y[..., :split], np.maximum(y[..., split:], 0)
+    else:
+        want1, want2 = (np.maximum(y, 0) if relu else y), None
+        if res is not None:
+            want1 = want1.astype(np.float16).astype(np.float64) + res.astype(np.float64)   # fp16(conv + bias), then the fp16 Add
+    for got, want in ((g1, want1), (g2, want2)):
+        if want is None:
+            continue
+        got = got.cpu().double().numpy()
+        assert np.isfinite(got).all()
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err <= 2e-3, (name, err)
+    junk = torch.empty(32 << 20, dtype=torch.uint8, device=cuda)
+    for it in range(6):                               # race screen: bits must not depend on timing
+        if it % 2:
+            junk.fill_(it)
+        h1, h2 = run()
+        assert torch.equal(h1, g1) and (not split or torch.equal(h2, g2)), f'{name}: launch {it} differs'
+
+
+def test_conv_gemm8p_rejects_partial_tiles(lib, cuda):
+    d = H.conv_desc(1, 8, 512, 8, 256, 1)             # 64 pixels: not a whole 256-pixel tile
+    t = torch.zeros(1 << 20, dtype=torch.float16, device=cuda)
+    st = lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(t), H.ptr(t), H.ptr(t.float()), None, None, None, H.ptr(t), 0, None, C.c_void_p(0))
+    assert st == -2 and b'pixels' in lib.metro_last_error()

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Times metro_conv_f16_gemm8p (and metro_conv_f16 on the same layer) on the deep-K 1x1 shapes of blocks 3-4.
+    python tools/gemm8p_probe.py [batch]"""
+import ctypes as C
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+from metro_pose3d_amd import _lib
+from tests import helpers as H
+
+lib = _lib.load()
+dev = torch.device('cuda', 0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+SHAPES = [(2048, 512), (1024, 256), (1024, 2048), (512, 1024), (1024, 512)]
+rng = np.random.default_rng(0)
+for c_in, c_out in SHAPES:
+    x = torch.from_numpy(rng.standard_normal((n, 16, 16, c_in)).astype(np.float16)).to(dev)
+    w = torch.from_numpy((rng.standard_normal((c_out, c_in)) * np.sqrt(2.0 / c_in)).astype(np.float16)).to(dev)
+    b = torch.zeros(c_out, dtype=torch.float32, device=dev)
+    sc = torch.ones(c_in, dtype=torch.float16, device=dev)
+    sh = torch.zeros(c_in, dtype=torch.float16, device=dev)
+    out = torch.empty((n, 16, 16, c_out), dtype=torch.float16, device=dev)
+    gf = 2.0 * n * 256 * c_in * c_out / 1e9
+    for pro in (False, True):
+        d = H.conv_desc(n, 16, c_in, 16, c_out, 1, prologue=pro)
+        res = {}
+        for name, fn in (('gemm8p', lambda: lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
+                                                                     H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
+                         ):
+            for _ in range(3):
+                assert fn() == 0, lib.metro_last_error()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            res[name] = e0.elapsed_time(e1) / reps * 1e3
+        print(f'n={n} {c_in:5d}->{c_out:5d} pro={int(pro)}  ' + '  '.join(f'{k} {v:7.1f} us {gf / v * 1e3:6.0f} TF/s' for k, v in res.items()), flush=True)
