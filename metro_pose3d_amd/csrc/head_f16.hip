@@ -1,0 +1,268 @@
+// The volumetric head in ONE launch: postnorm BN + ReLU (prologue) -> 1x1 logits convolution + bias -> per-joint
+// softmax statistics over the tile's voxels, for heads of up to 160 channels (17- and 19-joint heads at depth 8).
+//
+// Reference: resnet_v2.py:229-236 (postnorm, logits), architectures.py:34 (cast to fp32), volumetric.py:227-235
+// (reshape [D, J] -> softmax over (H, W, D) per joint -> decode_heatmap), tfu.py:466-499.
+//
+// Before, the logits (8.9 MB fp32 at RN50-s16 batch 64, 35.7 MB at stride 4) went to HBM and came back into a
+// separate soft-argmax launch.  Here a block owns 64 pixels of ONE image and ALL head channels:
+//   * GEMM [C <= 160 channels] x [64 pixels] x K (2048): LDS-DMA ring (5 stages of 28 KiB, counted vmcnt waits, one
+//     s_barrier per 64-channel K step; four steps = 112 KiB in flight per CU: these blocks stream 0.8 MB each and
+//     are latency bound), 8 waves = 4 K-quarters x 2 pixel tiles, v_mfma_f32_32x32x16_f16, fp32 accumulators; the
+//     pre-activation is applied to the pixel fragments in fp16 like every other consumer of the residual stream; the
+//     K-quarters are added through LDS in a fixed order;
+//   * the fp32 logits tile stays in LDS ([pixel][channel], odd row pitch: conflict-free column reads).  Channel
+//     c = d * J + j (volumetric.py:231).  Wave w takes joints w, w + 8, ...: a lane owns 1 pixel x D depths of the
+//     joint, the tile maximum and the four sums (S, Sx, Sy, Sz) are folded across the 64 lanes with wave shuffles
+//     (__shfl_xor -> DPP / ds_bpermute, no LDS round trip, no serial loop) -- max first, then exp(l - max): exact
+//     two-pass softmax on the tile, one (m, S, Sx, Sy, Sz) record per (image, 64-pixel slab, joint);
+//   * softargmax_finalize (pool_softargmax.hip) folds the slabs, decodes to millimetres, subtracts the root joint
+//     and gathers the exported order, as for the two-launch path.
+// The logits never exist in HBM.  Arithmetic: fp16 operands, fp32 accumulate, fp32 bias add, fp32 soft-argmax.
+#include "metro_common.h"
+
+namespace metro {
+
+typedef _Float16 half_t;
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page_head[4];   // zero-initialised
+
+namespace hd {
+constexpr int TM = 160, MT = 5, TN = 64, BK = 64, NW = 8, NT = 512, STAGES = 5;
+constexpr int KH = 4;                                  // K-quarters of every step (one 16-channel MFMA k step each)
+constexpr int ROW_BYTES = BK * 2;
+constexpr int STAGE_BYTES = (TM + TN) * ROW_BYTES;     // 28 KiB
+constexpr int RING_BYTES = STAGES * STAGE_BYTES;       // 140 KiB: four K steps (112 KiB) in flight per CU
+constexpr int LROW = 161;                              // fp32 words per logits-tile row (odd: conflict-free columns)
+constexpr int LOGITS_BYTES = TN * LROW * 4;            // 41 KiB, overlays the ring after the K loop
+constexpr int PRO_BYTES = 2 * 2048 * 2;
+constexpr int LDS_BYTES = RING_BYTES + PRO_BYTES;
+constexpr int LPS_A = 5, LPS_B = 2;                    // DMA instructions per K step: waves 0-3 (weights) / 4-7 (pixels)
+static_assert(LOGITS_BYTES <= RING_BYTES, "logits tile must fit the ring");
+}  // namespace hd
+
+__device__ __forceinline__ int hd_swz(int row) { return (row >> 1) & 7; }
+typedef __attribute__((address_space(3))) void hd_lds_void_t;
+
+__device__ __forceinline__ void hd_dma16(const void* gsrc, unsigned lds_addr) {
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(gsrc), "s"(lds_addr));
+}
+template <int N>
+__device__ __forceinline__ void hd_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+struct HeadArgs {
+    const half_t* x;          // [n * pixels][K] fp16, raw residual stream
+    const half_t* w;          // [C][K] fp16
+    const float* bias;        // [C]
+    const half_t* pro_scale;  // [K] postnorm scale / shift (fp16)
+    const half_t* pro_shift;
+    float* partials;          // [n][slabs][J][5]: m, S, Sx, Sy, Sz
+    float* logits_out;        // optional fp32 NHWC logits [n * pixels][C] (tests / layer dumps); NULL in the product path
+    int K, C, J, D, side, pixels, slabs;
+};
+
+__global__ __launch_bounds__(hd::NT) void head_f16_kernel(HeadArgs a) {
+    using namespace hd;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 1, wn = wave & 1;      // K-quarter of every step, 32-pixel tile
+    const int slab = blockIdx.x, img = blockIdx.y;
+    const int m0 = img * a.pixels + slab * TN;    // first pixel row of the tile
+    const int K = a.K, nk = K / BK;
+    const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page_head);
+    const unsigned smem_base = (unsigned)(size_t)(hd_lds_void_t*)smem;
+    half_t* pro_lds = reinterpret_cast<half_t*>(smem + RING_BYTES);
+
+    // ---- DMA sources: waves 0-3 bring the 160 weight rows (20 groups of 8 rows, 5 per wave), waves 4-7 the 64 pixel rows
+    const int lrow = lane >> 3, lch = lane & 7;
+    const half_t* src[LPS_A];
+    int inc[LPS_A];
+    unsigned ldsoff[LPS_A];
+    const int nld = wave < 4 ? LPS_A : LPS_B;
+#pragma unroll
+    for (int i = 0; i < LPS_A; ++i) {
+        if (wave < 4) {
+            const int row = (i * 4 + wave) * 8 + lrow;
+            const bool ok = row < a.C;
+            src[i] = ok ? a.w + (size_t)row * K + ((lch ^ hd_swz(row)) * 8) : zero;
+            inc[i] = ok ? BK : 0;
+            ldsoff[i] = (i * 4 + wave) * 8 * ROW_BYTES;
+        } else {
+            const int g = (i * 4 + (wave - 4)) & 7;              // 8 groups of 8 pixel rows, 2 per wave
+            const int row = g * 8 + lrow;
+            src[i] = a.x + (size_t)(m0 + row) * K + ((lch ^ hd_swz(row)) * 8);
+            inc[i] = BK;
+            ldsoff[i] = TM * ROW_BYTES + g * 8 * ROW_BYTES;
+        }
+    }
+    auto issue_step = [&](int slot) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES);
+#pragma unroll
+        for (int i = 0; i < LPS_A; ++i) {
+            if (i < nld) {                        // wave-uniform: the pixel waves issue 2, the weight waves 5
+                hd_dma16(src[i], base + ldsoff[i]);
+                src[i] += inc[i];
+            }
+        }
+    };
+
+    floatx16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+
+    // ---- ring prologue, postnorm table ----
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue_step(s);
+    for (int c = tid * 8; c < K; c += NT * 8) {
+        *reinterpret_cast<uint4*>(pro_lds + c) = *reinterpret_cast<const uint4*>(a.pro_scale + c);
+        *reinterpret_cast<uint4*>(pro_lds + 2048 + c) = *reinterpret_cast<const uint4*>(a.pro_shift + c);
+    }
+    __syncthreads();      // table visible (drains the DMAs issued so far as well: once per block)
+
+    const int brow = wn * 32 + frag_row;
+    const int b_off = TM * ROW_BYTES + brow * ROW_BYTES;
+    const int b_sw = hd_swz(brow);
+    auto compute_step = [&](int slot, int k0) {
+        const char* wl = smem + slot * STAGE_BYTES;
+        {
+            const int kk = kh;
+            const int chunk = kk * 2 + frag_half;
+            half8_t bf = *reinterpret_cast<const half8_t*>(wl + b_off + ((chunk ^ b_sw) << 4));
+            const half8_t sc = *reinterpret_cast<const half8_t*>(pro_lds + k0 + chunk * 8);
+            const half8_t sh = *reinterpret_cast<const half8_t*>(pro_lds + 2048 + k0 + chunk * 8);
+            const half8_t z = {};
+            bf = __builtin_elementwise_max(bf * sc + sh, z);      // postnorm BN + ReLU, fp16 FMA (resnet_v2.py:229)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = i * 32 + frag_row;
+                const half8_t af = *reinterpret_cast<const half8_t*>(wl + row * ROW_BYTES + ((chunk ^ hd_swz(row)) << 4));
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[i], 0, 0, 0);
+            }
+        }
+    };
+    // steady state: STAGES-2 younger steps stay in flight; per-wave DMA counts differ between the two loader groups
+    const int n_main = nk - (STAGES - 1);
+    int slot = 0, islot = STAGES - 1;
+    for (int k = 0; k < n_main; ++k) {
+        if (wave < 4) hd_wait_barrier<(STAGES - 2) * LPS_A>(); else hd_wait_barrier<(STAGES - 2) * LPS_B>();
+        issue_step(islot);
+        compute_step(slot, k * BK);
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+        islot = islot + 1 == STAGES ? 0 : islot + 1;
+    }
+    for (int k = n_main < 0 ? 0 : n_main; k < nk; ++k) {      // drain
+        const int ahead = nk - 1 - k;
+        if (ahead >= 3) { if (wave < 4) hd_wait_barrier<3 * LPS_A>(); else hd_wait_barrier<3 * LPS_B>(); }
+        else if (ahead == 2) { if (wave < 4) hd_wait_barrier<2 * LPS_A>(); else hd_wait_barrier<2 * LPS_B>(); }
+        else if (ahead == 1) { if (wave < 4) hd_wait_barrier<LPS_A>(); else hd_wait_barrier<LPS_B>(); }
+        else hd_wait_barrier<0>();
+        compute_step(slot, k * BK);
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+    __syncthreads();      // every wave is done with the ring: the logits tile overlays it
+
+    // ---- the four K-quarters -> fp32 logits tile [pixel][channel] (+bias), added in a FIXED order (bit-reproducible) ----
+    float* lt = reinterpret_cast<float*>(smem);
+    const int prow = wn * 32 + frag_row;
+#pragma unroll
+    for (int r = KH - 1; r >= 0; --r) {
+        if (kh == r) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = i * 32 + 8 * q + 4 * frag_half + e;
+                        float v = acc[i][4 * q + e];
+                        if (r != KH - 1) v += lt[prow * LROW + c];
+                        if (r == 0) v += c < a.C ? a.bias[c] : 0.f;
+                        lt[prow * LROW + c] = v;
+                    }
+        }
+        __syncthreads();
+    }
+    if (a.logits_out != nullptr) {                // layer dump for the tests: coalesced rows of C floats
+        for (int idx = tid; idx < TN * a.C; idx += NT) {
+            const int p = idx / a.C, c = idx - p * a.C;
+            a.logits_out[(size_t)(m0 + p) * a.C + c] = lt[p * LROW + c];
+        }
+    }
+
+    // ---- per-joint softmax statistics of the tile: wave shuffles ----
+    // lane <-> pixels (lane, lane + 64); coordinates in fp32 like tf.linspace (tfu.py:481)
+    const float step_s = 1.0f / (float)(a.side - 1);
+    const float step_d = 1.0f / (float)(a.D - 1);
+    const int pim = slab * TN + lane;                     // pixel index inside the image
+    const int py = pim / a.side, px = pim - py * a.side;
+    const float cx = (float)px * step_s, cy = (float)py * step_s;
+    for (int j = wave; j < a.J; j += NW) {
+        float m = -INFINITY;
+        for (int d = 0; d < a.D; ++d) m = fmaxf(m, lt[lane * LROW + d * a.J + j]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float s = 0.f, sz = 0.f;
+        for (int d = 0; d < a.D; ++d) {
+            const float e = __expf(lt[lane * LROW + d * a.J + j] - m);
+            s += e;
+            sz += e * ((float)d * step_d);
+        }
+        float sx = s * cx, sy = s * cy;                   // the pixel's coordinates are the lane's
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            sx += __shfl_xor(sx, o, 64);
+            sy += __shfl_xor(sy, o, 64);
+            sz += __shfl_xor(sz, o, 64);
+        }
+        if (lane == 0) {
+            float* o5 = a.partials + (((size_t)img * a.slabs + slab) * a.J + j) * 5;
+            o5[0] = m; o5[1] = s; o5[2] = sx; o5[3] = sy; o5[4] = sz;
+        }
+    }
+}
+
+// heads this launch is built for: fp16 input, whole 128-pixel slabs per image, at most 160 channels, K in whole steps
+bool head_f16_supported(int c_in, int c_head, int n_joints, int depth, int side) {
+    static const int enabled = tuning_knob("METRO_HEAD_FUSED", 1);
+    const int pixels = side * side;
+    return enabled && c_head == n_joints * depth && c_head <= hd::TM && c_in % hd::BK == 0 && c_in <= 2048 &&
+           c_in / hd::BK >= hd::STAGES - 1 && pixels % hd::TN == 0 && side >= 2 && depth >= 2;
+}
+int head_f16_slabs(int side) { return side * side / hd::TN; }
+
+int launch_head_f16(const void* x, const void* w, const float* bias, const void* pro_scale, const void* pro_shift,
+                    int n, int c_in, int c_head, int n_joints, int depth, int side, float* partials, float* logits_out,
+                    hipStream_t stream) {
+    if (!head_f16_supported(c_in, c_head, n_joints, depth, side)) {
+        set_error("head_f16: unsupported head (c_in %d, %d channels = %d joints x depth %d, side %d)", c_in, c_head, n_joints, depth, side);
+        return METRO_ERR_UNSUPPORTED;
+    }
+    HeadArgs a;
+    a.x = static_cast<const half_t*>(x); a.w = static_cast<const half_t*>(w); a.bias = bias;
+    a.pro_scale = static_cast<const half_t*>(pro_scale); a.pro_shift = static_cast<const half_t*>(pro_shift);
+    a.partials = partials; a.logits_out = logits_out;
+    a.K = c_in; a.C = c_head; a.J = n_joints; a.D = depth; a.side = side; a.pixels = side * side; a.slabs = head_f16_slabs(side);
+    static PerDeviceInt done;
+    if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(head_f16_kernel), hd::LDS_BYTES, done, "head_f16")) return st;
+    hipLaunchKernelGGL(head_f16_kernel, dim3(a.slabs, n), dim3(hd::NT), hd::LDS_BYTES, stream, a);
+    return launch_status("head_f16");
+}
+
+}  // namespace metro

@@ -214,6 +214,15 @@ int softargmax_slabs(int n, int side);
 int64_t softargmax_scratch_bytes(int n, int side, int n_joints_head);
 int launch_softargmax(const void* logits, const SoftArgmaxArgs& a, int precise, void* partials,
                       float* poses_out, hipStream_t stream, float* coords01_out = nullptr);
+// finalize only (slabs folded, mm decode, root-relative, permutation) on fp32 partials written by another kernel
+int launch_softargmax_finalize(const float* partials, const SoftArgmaxArgs& a, int slabs, float* poses_out,
+                               hipStream_t stream, float* coords01_out = nullptr);
+// the volumetric head in one launch (head_f16.hip): postnorm prologue + logits GEMM + per-joint softmax statistics
+bool head_f16_supported(int c_in, int c_head, int n_joints, int depth, int side);
+int head_f16_slabs(int side);
+int launch_head_f16(const void* x, const void* w, const float* bias, const void* pro_scale, const void* pro_shift,
+                    int n, int c_in, int c_head, int n_joints, int depth, int side, float* partials, float* logits_out,
+                    hipStream_t stream);
 // alternative decode heads (heads.hip): root_z != NULL selects true-root-depth, else the bone-length solve
 int launch_backproject(const float* coords01, const float* inv_k, const double* targets, int per_pose_targets,
                        const float* root_z, const int* edges, int n, int nj, int ne, const MetroSpec& spec,

@@ -72,6 +72,8 @@ struct Layer {
     // conv3 of unit u + conv1 of unit u+1 (ConvFuse2): parameter indices of the second GEMM, -1 = none
     int f2_w, f2_bias, f2_scale, f2_shift, f2_c2;
     int stem_pool;        // stem conv + max-pool in one launch (the layer's output is the pooled tensor)
+    int head_fused;       // logits layer: GEMM + per-joint softmax statistics in one launch (head_f16.hip); the
+                          // soft-argmax layer behind it then only finalizes
 };
 
 }  // namespace
@@ -453,6 +455,9 @@ int build_plan(MetroPlan* p) {
     const int c_head = sp.depth * sp.n_joints_head;
     B.add_conv("logits", "logits", "", "postnorm", cur, S_LOGITS, S_NONE, cur_side, cur_c, cur_side,
                c_head, 1, 1, 1, 0, false, 0, 1, 0, ldt, adt);
+    // fp16 mode: the logits stay on chip (volumetric.py:227-235 starts in the GEMM's epilogue)
+    const bool head_fused = fast && head_f16_supported(cur_c, c_head, sp.n_joints_head, sp.depth, cur_side);
+    p->layers.back().head_fused = head_fused ? 1 : 0;
 
     // ---- soft-argmax + decode ---------------------------------------------------------------
     {
@@ -464,6 +469,7 @@ int build_plan(MetroPlan* p) {
         L.cd.c_out = 3; L.cd.out_dtype = METRO_F32;
         L.in_slot = S_LOGITS; L.out_slot = S_NONE; L.res_slot = S_NONE;
         L.p_w = L.p_bias = L.p_scale = L.p_shift = -1;
+        L.head_fused = head_fused ? 1 : 0;
         B.fill_info(L, "softargmax", 0.0);
         p->layers.push_back(L);
     }
@@ -495,6 +501,11 @@ int build_plan(MetroPlan* p) {
         else act += L.info.out_bytes_per_image;
         if (two) act += (int64_t)L.cd.h_out * L.cd.w_out * L.info.out2_channels * es;
         if (L.kind == LK_CONV && L.cd.has_residual) act += (int64_t)L.cd.h_out * L.cd.w_out * L.cd.c_out * es;
+        if (L.head_fused) {       // logits never reach HBM: the launch writes / the finalize reads the per-slab statistics
+            const int64_t part = (int64_t)head_f16_slabs(sp.proc_side / sp.stride) * sp.n_joints_head * 5 * 4;
+            if (L.kind == LK_CONV) act = (int64_t)L.cd.h_in * L.cd.w_in * L.cd.c_in * 2 + part;
+            else act = part + (int64_t)sp.n_joints_out * 3 * 4;
+        }
         L.info.algo_act_bytes_per_image = act;
         int64_t pb = 0;
         for (int idx : {L.p_w, L.p_bias, L.p_scale, L.p_shift, L.f2_w, L.f2_bias, L.f2_scale, L.f2_shift})
@@ -542,7 +553,13 @@ int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_
             case LK_CONV: {
                 MetroConvDesc cd = L.cd;
                 cd.n = n;
-                if (p->fast && L.stem_pool == 2) {
+                if (p->fast && L.head_fused) {
+                    // layer dumps (metro_forward_upto stopping here) also get the fp32 logits tensor
+                    float* dump = li == last_layer && li + 1 < nl ? static_cast<float*>(slot_ptr(L.out_slot)) : nullptr;
+                    st = launch_head_f16(slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)), prm(L.p_scale),
+                                         prm(L.p_shift), n, L.cd.c_in, L.cd.c_out, p->spec.n_joints_head, p->spec.depth, L.cd.h_in,
+                                         static_cast<float*>(slot_ptr(S_PART)), dump, stream);
+                } else if (p->fast && L.stem_pool == 2) {
                     st = launch_stem_pool_f32in(images, prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
                                                 slot_ptr(L.out_slot), n, p->spec.proc_side, stream);
                 } else if (p->fast && L.stem_pool) {
@@ -577,8 +594,10 @@ int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_
             case LK_SOFTARGMAX: {
                 if (poses == nullptr) { set_error("metro_forward: poses_out is NULL"); st = METRO_ERR_INVALID_ARG; break; }
                 const SoftArgmaxArgs a = make_softargmax_args(p->spec, n);
-                st = launch_softargmax(slot_ptr(L.in_slot), a, p->spec.precision,
-                                       slot_ptr(S_PART), poses, stream);
+                if (L.head_fused)
+                    st = launch_softargmax_finalize(static_cast<const float*>(slot_ptr(S_PART)), a, head_f16_slabs(a.side), poses, stream);
+                else
+                    st = launch_softargmax(slot_ptr(L.in_slot), a, p->spec.precision, slot_ptr(S_PART), poses, stream);
                 break;
             }
         }

@@ -378,6 +378,12 @@ static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void
     return launch_status("softargmax_finalize");
 }
 
+int launch_softargmax_finalize(const float* partials, const SoftArgmaxArgs& a, int slabs, float* poses_out,
+                               hipStream_t stream, float* coords01_out) {
+    hipLaunchKernelGGL(softargmax_finalize_kernel<float>, dim3(a.n), dim3(64), 0, stream, partials, poses_out, a, slabs, coords01_out);
+    return launch_status("softargmax_finalize");
+}
+
 int launch_softargmax(const void* logits, const SoftArgmaxArgs& a, int precise, void* partials,
                       float* poses_out, hipStream_t stream, float* coords01_out) {
     const int C = a.depth * a.n_joints_head;

@@ -131,6 +131,6 @@ def test_hip_softargmax_reproduces_golden(gold, cuda, lib):
         spec = ModelSpec(**meta[name]['spec'])
         lg = (np.random.default_rng(77).standard_normal(
             (2, spec.heatmap_side, spec.heatmap_side, spec.n_head_channels)) * 4).astype(np.float32)
-        for precise, tol in ((0, 5e-2), (1, 1e-3), (2, 1e-3)):
+        for precise, tol in ((0, 1e-3), (1, 1e-3), (2, 1e-3)):
             got = H.run_softargmax(lib, cuda, spec, lg, precise)
             assert np.abs(got - z[name + '/poses']).max() <= tol

@@ -315,7 +315,7 @@ def test_softargmax_random(lib, cuda, spec, precise):
     logits = (rng.standard_normal((n, s, s, c)) * 4).astype(np.float32)
     got = H.run_softargmax(lib, cuda, spec, logits, precise)
     ref = logits_to_output(H.oracle_spec(spec), logits).numpy()
-    tol = 1e-3 if precise else 5e-2       # mm; fp32 accumulation of 8*S*S terms in fast mode
+    tol = 1e-3 if precise else 2e-3       # mm; fast mode: fp32 accumulation of 8*S*S terms (measured 2-7e-4 on the nets, <= 1.5e-3 on these N(0,4) logits)
     assert np.abs(got - ref).max() <= tol, np.abs(got - ref).max()
 
 
@@ -357,7 +357,7 @@ def test_softargmax_online_rescale_branch(lib, cuda):
     for precise in (0, 1, 2):
         got = H.run_softargmax(lib, cuda, spec, logits, precise)
         ref = logits_to_output(H.oracle_spec(spec), logits).numpy()
-        assert np.abs(got - ref).max() <= (1e-3 if precise else 5e-2)
+        assert np.abs(got - ref).max() <= (1e-3 if precise else 2e-3)
 
 
 def test_error_reporting(lib):
