@@ -8,18 +8,25 @@ tensorflow/core/framework/{graph,node_def,attr_value,tensor,tensor_shape,types}.
 
 What is extracted:
   * every `Const` node's tensor (DT_FLOAT / DT_HALF / DT_INT32 / DT_INT64 / DT_STRING), by node name;
-  * the slim variables of the backbone + head, found by their variable names
-    `MainPart/resnet_v2_{50,101}/.../{weights,biases,gamma,beta,moving_mean,moving_variance}`
-    (scopes: reference volumetric.py:158, architectures.py:24, resnet_v2.py:117-136,203-236).
-    `fold_constants` may replace a `Cast(variable)` by a new Const whose name starts with the
-    variable's name (main.py:150-157 runs it; tfu.py:426-440 inserts the casts): any Const whose
-    name equals the variable name or extends it with '/...' is accepted, fp32 preferred;
+  * the slim variables of the backbone + head, found by GRAPH STRUCTURE first: every Conv2D / BiasAdd /
+    FusedBatchNorm[V2/V3] node's parameter inputs are followed back through Identity (`.../read`) and Cast nodes to
+    the Const that feeds them -- the original fp32 variable, or the fp16 Const that `fold_constants` (main.py:150-157)
+    leaves in place of `Cast(variable)` (tfu.py:426-440 casts every trainable variable at use, so in the default
+    fp16 export the surviving constant is named after the CAST node, e.g. `.../conv1/Cast/_12__cf__12`, not after
+    the variable).  The slim variable name is taken from the chain when one of its nodes still carries it, else from
+    the consumer: `<scope of the op>/{weights | biases | gamma, beta, moving_mean, moving_variance}` by input
+    position (scopes: reference volumetric.py:158, architectures.py:24, resnet_v2.py:117-136,203-236);
+    graphs that are plain bags of constants (the in-repo writer) are read by variable name as before;
+  * `centered_stride` (options.py:118) is not stored in a graph; it is inferred from the one place it changes the
+    ops: the strided 3x3 conv2 of a bottleneck is `padding='SAME'` when centered and an explicit Pad + 'VALID'
+    otherwise (resnet_utils.py:120-135).  Graphs without a strided unit (stride 4) keep the caller's value;
   * `joint_names` / `joint_edges` (main.py:140-141) and, when present, the 5-element Reshape shape
     `[-1, depth, J, S, S]` of volumetric.py:231 from which depth, J_head and the stride follow.
 
-There is no released `.pb` offline to try this on, so the reader is exercised against files made
-by `write_frozen_graph` below (same wire format, fp32 and fp16-folded variants); real-model
-quirks not covered by those tests are possible and are reported as errors, never guessed around.
+UNTESTED AGAINST A REAL EXPORT: there is no released `.pb` (and no TensorFlow) offline.  The reader is exercised
+against graphs encoded with the official protobuf runtime that are shaped like a TF 1.13 export of this model
+(variable -> read -> Cast -> [folded] -> Conv2D / BiasAdd / FusedBatchNorm, fp32 and fp16-folded; tests/test_tfgraph.py)
+and against the in-repo writer; anything it cannot identify is reported as an error, never guessed around.
 """
 from __future__ import annotations
 
@@ -196,12 +203,107 @@ def read_graph(path: str) -> Dict[str, Node]:
 
 # ---- GraphDef -> (ModelSpec, slim variable dict) ------------------------------------------------------
 _VAR_RE = re.compile(r'^(MainPart/resnet_v2_(50|101)/.*?/(weights|biases|gamma|beta|moving_mean|moving_variance))(/.*)?$')
+_KINDS = ('weights', 'biases', 'gamma', 'beta', 'moving_mean', 'moving_variance')
+_FOLD_RE = re.compile(r'/_\d+__cf__\d+$')                      # suffix fold_constants gives the constants it creates
+_PASS_RE = re.compile(r'/(read|Identity|Cast(_\d+)?)$')
+# op -> {input index: variable kind}
+_PARAM_INPUTS = {'Conv2D': {1: 'weights'}, 'BiasAdd': {1: 'biases'},
+                 'FusedBatchNorm': {1: 'gamma', 2: 'beta', 3: 'moving_mean', 4: 'moving_variance'}}
+_PARAM_INPUTS['FusedBatchNormV2'] = _PARAM_INPUTS['FusedBatchNormV3'] = _PARAM_INPUTS['FusedBatchNorm']
 
 
-def extract_model(nodes: Dict[str, Node], stride: Optional[int] = None, centered_stride: bool = True):
+def _attr_string(raw: Optional[bytes]) -> Optional[str]:
+    """AttrValue.s (field 2)."""
+    if raw is None:
+        return None
+    for fno, wt, v in _fields(memoryview(raw)):
+        if fno == 2 and wt == _LEN:
+            return bytes(v).decode()
+    return None
+
+
+def _attr_ints(raw: Optional[bytes]) -> List[int]:
+    """AttrValue.list.i (field 1 -> ListValue field 3, packed or repeated)."""
+    out: List[int] = []
+    if raw is None:
+        return out
+    for fno, wt, v in _fields(memoryview(raw)):
+        if fno == 1 and wt == _LEN:
+            for f2, w2, v2 in _fields(v):
+                if f2 == 3 and w2 == _LEN:
+                    p = 0
+                    while p < len(v2):
+                        x, p = _read_varint(v2, p)
+                        out.append(_signed64(x))
+                elif f2 == 3 and w2 == _VARINT:
+                    out.append(_signed64(v2))
+    return out
+
+
+def _producer(nodes: Dict[str, 'Node'], ref: str) -> Optional['Node']:
+    name = ref[1:] if ref.startswith('^') else ref
+    return nodes.get(name.split(':')[0])
+
+
+def _variable_name(chain: List[str], consumer: 'Node', kind: str) -> str:
+    """Slim variable name of a parameter reached through `chain` (node names, constant first)."""
+    for name in chain:
+        base = _FOLD_RE.sub('', name)
+        while _PASS_RE.search(base):
+            base = _PASS_RE.sub('', base)
+        if base.rsplit('/', 1)[-1] in _KINDS:
+            return base
+    return consumer.name.rsplit('/', 1)[0] + '/' + kind      # '<layer scope>/Conv2D' -> '<layer scope>/weights'
+
+
+def structural_params(nodes: Dict[str, 'Node']) -> Dict[str, np.ndarray]:
+    """Parameters identified by what consumes them (module docstring)."""
+    found: Dict[str, np.ndarray] = {}
+    for n in nodes.values():
+        for idx, kind in _PARAM_INPUTS.get(n.op, {}).items():
+            if idx >= len(n.inputs):
+                continue
+            chain: List[str] = []
+            cur = _producer(nodes, n.inputs[idx])
+            hops = 0
+            while cur is not None and cur.op in ('Identity', 'Cast', 'StopGradient') and cur.inputs and hops < 8:
+                chain.append(cur.name)
+                cur = _producer(nodes, cur.inputs[0])
+                hops += 1
+            if cur is None or cur.op != 'Const' or cur.tensor is None or cur.tensor.dtype not in (np.float32, np.float16):
+                continue                                        # an activation (e.g. a 1x1 conv of two tensors): not a parameter
+            chain.append(cur.name)
+            name = _variable_name(chain[::-1], n, kind)
+            t = cur.tensor
+            if name in found and not np.array_equal(np.asarray(found[name], np.float32), np.asarray(t, np.float32)):
+                raise ValueError(f'two different constants resolve to the variable {name!r}')
+            found[name] = t
+    return found
+
+
+def infer_centered_stride(nodes: Dict[str, 'Node'], params: Dict[str, np.ndarray]) -> Optional[bool]:
+    """True / False from the padding mode of a strided 3x3 bottleneck conv2, None when the graph has none."""
+    for n in nodes.values():
+        if n.op != 'Conv2D' or '/bottleneck_v2/conv2' not in n.name:
+            continue
+        strides = _attr_ints(n.attrs.get('strides'))
+        if len(strides) == 4 and max(strides) == 2:
+            pad = _attr_string(n.attrs.get('padding'))
+            if pad in ('SAME', 'VALID'):
+                return pad == 'SAME'
+    return None
+
+
+def extract_model(nodes: Dict[str, Node], stride: Optional[int] = None, centered_stride: Optional[bool] = None):
+    """centered_stride: None = infer from the graph (default True, options.py:118, when it has no strided unit)."""
     from metro_pose3d_amd.spec import ModelSpec
-    params: Dict[str, np.ndarray] = {}
+    params: Dict[str, np.ndarray] = dict(structural_params(nodes))
     arch = None
+    for k in params:
+        m = _VAR_RE.match(k)
+        if m:
+            arch = int(m.group(2))
+    structural = set(params)
     for name, n in nodes.items():
         if n.op != 'Const' or n.tensor is None:
             continue
@@ -209,6 +311,8 @@ def extract_model(nodes: Dict[str, Node], stride: Optional[int] = None, centered
         if not m or n.tensor.dtype not in (np.float32, np.float16):
             continue
         var = m.group(1)
+        if var in structural:
+            continue                                            # identified by its consumer already
         arch = int(m.group(2))
         exact = m.group(4) is None
         # prefer the original fp32 variable over a folded fp16 copy
@@ -251,6 +355,9 @@ def extract_model(nodes: Dict[str, Node], stride: Optional[int] = None, centered
             dataset = cand
     if dataset is None:
         raise ValueError(f'unrecognised skeleton: {len(out_names)} output joints {out_names[:4]}..., head {j_head}')
+    if centered_stride is None:
+        inferred = infer_centered_stride(nodes, params)
+        centered_stride = True if inferred is None else inferred
     spec = ModelSpec(arch=arch, stride=stride, dataset=dataset, depth=depth, centered_stride=centered_stride,
                      base_width=base_width)
     edges = nodes.get('joint_edges')
@@ -260,7 +367,7 @@ def extract_model(nodes: Dict[str, Node], stride: Optional[int] = None, centered
     return spec, params
 
 
-def load_frozen_graph(path: str, stride: Optional[int] = None, centered_stride: bool = True):
+def load_frozen_graph(path: str, stride: Optional[int] = None, centered_stride: Optional[bool] = None):
     return extract_model(read_graph(path), stride=stride, centered_stride=centered_stride)
 
 
