@@ -340,7 +340,10 @@ bool conv_gemm8p_supported(const MetroConvDesc& d, const ConvSplit* split) {
     static const int min_k = tuning_knob("METRO_GEMM8P_MIN_K", 512);
     if (!enabled || !conv_gemm8p_shape_ok(d, split) || d.c_in < min_k) return false;
     const long m = (long)d.n * d.h_out * d.w_out;
-    return (long)(d.c_out / 256) * (m / 256) >= min_tiles;
+    const long tiles = (long)(d.c_out / 256) * (m / 256);
+    // measured (MI355X): K = 512 with barely one tile per CU loses to the 128 x 256 ring kernel (block3's pair at batch
+    // 64: 44 vs 41 us), at four tiles per CU it wins (batch 256: 125 vs 134 us)
+    return tiles >= min_tiles && (d.c_in >= 1024 || tiles >= 4 * min_tiles);
 }
 
 int launch_conv_gemm8p(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* ps,

@@ -751,6 +751,7 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
 // fp16 convolution dispatcher (metro_conv_f16 and every plain conv layer of the plan)
 int launch_conv_f16(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* ps,
                     const void* pb, const void* res, void* out, hipStream_t stream) {
+    if (conv3x3_c64_supported(d)) return launch_conv3x3_c64(d, in, w, bias, out, stream);
     if (conv3x3_slab_supported(d)) return launch_conv3x3_slab(d, in, w, bias, out, stream);
     if (conv_f16_dma_supported(d)) return launch_conv_f16_dma(d, in, w, bias, ps, pb, res, out, stream);
     set_error("conv_f16: unsupported layer (c_in %d must be a multiple of 8 and <= 2048, in_pix_stride %d of 4 (8 with a "

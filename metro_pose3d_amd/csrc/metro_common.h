@@ -188,6 +188,9 @@ int launch_stem_pool_f16(const void* prepped, const void* w, const float* bias, 
 bool stem_pool_f32in_supported(int side, int base_width);
 int launch_stem_pool_f32in(const float* images, const void* w, const float* bias, void* out, int n, int side,
                            hipStream_t stream);
+// persistent weight-resident 3x3 for the 64 -> 64 channel layers (conv3x3_c64.hip)
+bool conv3x3_c64_supported(const MetroConvDesc& d);
+int launch_conv3x3_c64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out, hipStream_t stream);
 // 3x3 stride-1 convs with tap reuse from an LDS-resident activation slab
 bool conv3x3_slab_supported(const MetroConvDesc& d);
 int launch_conv3x3_slab(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out,

@@ -46,6 +46,11 @@ CONV_CASES = [
     ('3x3_slab_cin96_cout192', 2, 16, 96, 192, 3, 1, 1, 1, 16),
     ('3x3_slab_rate2_512', 3, 16, 128, 256, 3, 1, 2, 2, 16),
     ('3x3_slab_32map', 2, 32, 128, 128, 3, 1, 1, 1, 32),
+    # persistent weight-resident 64 -> 64 kernel (conv3x3_c64.hip): blocks walk several 128-pixel tiles (image borders
+    # inside a block's range, halo rows shared between consecutive tiles), 64- / 32- / 16-wide maps
+    ('3x3_c64_many_tiles', 21, 64, 64, 64, 3, 1, 1, 1, 64),
+    ('3x3_c64_32map', 5, 32, 64, 64, 3, 1, 1, 1, 32),
+    ('3x3_c64_16map', 9, 16, 64, 64, 3, 1, 1, 1, 16),
 ]
 
 
