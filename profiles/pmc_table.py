@@ -35,7 +35,7 @@ def main():
     names = []
     for li in infos:
         names.append(li.name.decode())
-    two_launch_head = None
+    per = None
     merged = defaultdict(dict)
     meta = {}
     for p in sorted(os.listdir(base)):
@@ -43,11 +43,14 @@ def main():
         if not os.path.isdir(d) or not glob.glob(os.path.join(d, '*_counter_collection.csv')):
             continue
         rows = load(d)
-        if two_launch_head is None:        # batch >= 32 on <= 256 pixels: soft-argmax is one launch, else partial + finalize
-            two_launch_head = any('softargmax_finalize' in r['name'] for r in rows)
-            if two_launch_head:
+        if per is None:
+            # launches per forward = dispatches / forwards (one stem launch per forward); the soft-argmax layer is one
+            # launch (finalize) behind the fused head, two (partial + finalize) otherwise
+            n_fwd = sum(1 for r in rows if 'stem_pool' in r['name'] or 'prep_input' in r['name'])
+            per = len(rows) // max(n_fwd, 1)
+            if per == len(names) + 1:
                 names.append('softargmax_fin')
-            per = len(names)
+            assert per == len(names), (per, len(names))
         rows = rows[fwd * per:(fwd + 1) * per]
         for i, r in enumerate(rows):
             merged[i].update(r['c'])
