@@ -32,6 +32,18 @@ const char* get_error();
         }                                                                                  \
     } while (0)
 
+// Tuning knobs: compile-time constants in the product build.  A build with -DMETRO_TUNING_KNOBS (tools/
+// build_dbg_variants.sh, A/B timing runs) reads them from the environment instead; the product never calls getenv.
+inline int tuning_knob(const char* name, int dflt) {
+#ifdef METRO_TUNING_KNOBS
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 // ---- per-device one-time kernel setup -----------------------------------------------------------------------
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the occupancy query act on the CURRENT device's copy of a
 // kernel: a process that drives several GPUs (inference.py caches one Engine per device) must do them once per
@@ -79,6 +91,7 @@ inline int ensure_dyn_lds_and_grid_cap(const void* kern, int threads, int bytes,
         }
         int cus = 0, occ = 0;
         METRO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, slot));
+        if (const int lim = tuning_knob("METRO_CU_LIMIT", 0); lim > 0 && lim < cus) cus = lim;   // A/B builds: partitioned-GPU experiments
         METRO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, bytes));
         if (occ < 1) occ = 1;
         if (max_blocks_per_cu > 0 && occ > max_blocks_per_cu) occ = max_blocks_per_cu;
@@ -86,18 +99,6 @@ inline int ensure_dyn_lds_and_grid_cap(const void* kern, int threads, int bytes,
     }
     *grid_cap = cap.v[slot];
     return METRO_OK;
-}
-
-// Tuning knobs: compile-time constants in the product build.  A build with -DMETRO_TUNING_KNOBS (tools/
-// build_dbg_variants.sh, A/B timing runs) reads them from the environment instead; the product never calls getenv.
-inline int tuning_knob(const char* name, int dflt) {
-#ifdef METRO_TUNING_KNOBS
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-#else
-    (void)name;
-    return dflt;
-#endif
 }
 
 inline int launch_status(const char* what) {
