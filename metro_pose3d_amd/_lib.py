@@ -113,6 +113,9 @@ def load() -> C.CDLL:
         raise MetroError(
             f'{LIB_PATH} is missing: build it with `python -m metro_pose3d_amd.build` '
             '(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.')
+    # torch first: it brings its own HIP runtime; loading this library before torch would pull a second libamdhip64
+    # (the system one) into the process, whose kernels then see "no ROCm-capable device"
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError if the symbol is not exported
