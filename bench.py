@@ -184,8 +184,8 @@ def roofline_of(eng, images, gpu_ms_per_step: float, reps: int, layer_report=Non
                         f'{li.out_bytes_per_image * b / 1e6:.2f}\t{ab / 1e6:.2f}\t{(ab / 1e6 / ms if ms > 0 else 0):.0f}\n')
             f.write(f'TOTAL\t-\t{layer_ms.sum():.4f}\t{conv_flops / 1e9:.3f}\t{conv_flops / 1e9 / layer_ms.sum():.1f}\t-\t{algo_bytes / 1e6:.1f}\t-\n')
     return {'bound': 'mfma',
-            'kernel': f'conv launches of the forward ({n_conv} per forward: conv_igemm_f16_dma, conv3x3_f16_slab, conv_pw64, '
-                      f'bneck/stem/head fused kernels)',
+            'kernel': f'conv launches of the forward ({n_conv} per forward: conv_igemm_f16_dma, conv_gemm8p, conv3x3_f16_slab, '
+                      f'conv3x3_c64, conv_pw64, stem_pool_f16, head_f16)',
             'achieved': round(achieved, 2), 'peak': PEAK_F16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_F16_DENSE_TFLOPS, 4), 'traffic': None, 'traffic_note': None,
             'algorithmic_min_bytes': int(algo_bytes),
