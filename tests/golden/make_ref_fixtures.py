@@ -8,6 +8,12 @@ Two pieces of the reference need nothing but NumPy / SciPy and therefore CAN run
   * src/model/bone_length_based_backproj.py: optimize_z_offset_by_bones_single (:38-62).  Its module imports
     TensorFlow at the top, so the function's own source lines are cut out with `ast` and executed in a namespace
     that holds `np` and `scipy` (nothing else is referenced by the function).
+  * the joint tables: class JointInfo (src/data/datasets.py:52-109) is cut out with `ast` (its module needs packages that
+    are absent here) and executed with the reference's own `util.invert_permutation` (src/util.py imports) and stdlib
+    equivalents of the two third-party helpers it touches (`more_itertools.pairwise` == `itertools.pairwise`, `AttrDict` ==
+    a dict); the joint-name / edge literals are read from make_h36m (src/data/h36m.py:25-31) and make_merged
+    (src/data/datasets.py:142-154), the export permutations from export() (src/main.py:119-125), all through `ast`.
+    Stored: head names, head edges, mirror mapping, permutation, exported names and re-indexed edges per dataset.
 Only inputs and the reference's outputs are stored (data, not source); the reference never travels.  The tests
 (tests/test_ref_fixtures.py) pin oracle/metrics.py, oracle/heads.py and the HIP kernels of rows f3/f4 to these vectors.
 """
@@ -47,6 +53,51 @@ def load_bone_solver():
     ns = {'np': np, 'scipy': scipy}
     exec(code, ns)
     return ns['optimize_z_offset_by_bones_single']
+
+
+def reference_joint_tables():
+    """{dataset: dict of arrays} computed by the reference's JointInfo / permute_joints (main.py:119-141)."""
+    import itertools
+    import types
+    sys.path.insert(0, os.path.join(REF, 'src'))
+    import util as ref_util                                   # src/util.py: imports without TensorFlow
+    ds_src = open(os.path.join(REF, 'src/data/datasets.py')).read()
+    ds_tree = ast.parse(ds_src)
+    cls = next(n for n in ds_tree.body if isinstance(n, ast.ClassDef) and n.name == 'JointInfo')
+
+    class AttrDict(dict):
+        pass
+    ns = {'np': np, 'itertools': itertools, 'util': ref_util, 'AttrDict': AttrDict,
+          'more_itertools': types.SimpleNamespace(pairwise=itertools.pairwise)}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), 'datasets.py', 'exec'), ns)
+    JointInfo = ns['JointInfo']
+
+    def assigned(tree, func, name):
+        fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == func)
+        node = next(n for n in ast.walk(fn) if isinstance(n, ast.Assign) and getattr(n.targets[0], 'id', None) == name)
+        return eval(compile(ast.Expression(node.value), func, 'eval'), {})
+
+    h36m_tree = ast.parse(open(os.path.join(REF, 'src/data/h36m.py')).read())
+    heads = {'h36m': (assigned(h36m_tree, 'make_h36m', 'joint_names'), assigned(h36m_tree, 'make_h36m', 'edges')),
+             'merged': (assigned(ds_tree, 'make_merged', 'joint_names'), assigned(ds_tree, 'make_merged', 'edges'))}
+    main_tree = ast.parse(open(os.path.join(REF, 'src/main.py')).read())
+    export = next(n for n in ast.walk(main_tree) if isinstance(n, ast.FunctionDef) and n.name == 'export')
+    perms = {}
+    for node in ast.walk(export):                              # if FLAGS.dataset == '<name>': permutation = [...]
+        if isinstance(node, ast.If) and isinstance(node.test, ast.Compare) and isinstance(node.test.comparators[0], ast.Constant):
+            for st in node.body:
+                if isinstance(st, ast.Assign) and getattr(st.targets[0], 'id', None) == 'permutation':
+                    perms[node.test.comparators[0].value] = ast.literal_eval(st.value)
+    out = {}
+    for ds, (names, edges) in heads.items():
+        ji = JointInfo(names, edges)
+        pj = ji.permute_joints(perms[ds])
+        out[ds] = {'head_names': np.array([n.encode() for n in ji.names]),
+                   'head_edges': np.array([tuple(e) for e in ji.stick_figure_edges], np.int64),
+                   'mirror': np.array(ji.mirror_mapping, np.int64), 'permutation': np.array(perms[ds], np.int64),
+                   'out_names': np.array([n.encode() for n in pj.names]),
+                   'out_edges': np.array([tuple(int(x) for x in e) for e in pj.stick_figure_edges], np.int64)}
+    return out
 
 
 def rot(rng):
@@ -101,6 +152,9 @@ def main():
         z_true = np.array([solve(x[i], delta_z[i], bones[i], H36M_EDGES) for i in range(m)])
     out.update({'bl/coords01': c01, 'bl/inv_intrinsics': inv_k, 'bl/stride': np.int32(stride), 'bl/x': x, 'bl/delta_z': delta_z, 'bl/edges': np.array(H36M_EDGES, np.int32), 'bl/target_mean': target_mean,
                 'bl/target_per_pose': bones, 'bl/z_mean_targets': z_mean, 'bl/z_per_pose_targets': z_true})
+    for ds, tab in reference_joint_tables().items():
+        for k, v in tab.items():
+            out[f'joints/{ds}/{k}'] = v
     out['versions'] = np.array([np.__version__, scipy.__version__])
     np.savez_compressed(OUT, **out)
     print(f'wrote {OUT} ({os.path.getsize(OUT) / 1024:.1f} KiB); numpy {np.__version__}, scipy {scipy.__version__}')

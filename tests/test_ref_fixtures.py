@@ -97,3 +97,28 @@ def test_hip_bone_length_solve_matches_reference(cuda, ref):
         assert np.abs(z.cpu().numpy() - zref).max() <= 2.5e-4 * 2, np.abs(z.cpu().numpy() - zref).max()   # <= one fp32 ulp at ~4 m
         want = OH.back_project(ref['bl/x'], ref['bl/delta_z'], zref)
         assert np.abs(got.cpu().numpy() - want).max() <= 2e-3
+
+
+# ---- joint tables computed by the reference's own JointInfo / permute_joints code ------------------------------------
+@pytest.mark.parametrize('dataset', ['h36m', 'merged'])
+def test_joint_tables_match_reference(ref, dataset):
+    """reference datasets.py:52-109 (JointInfo), h36m.py:25-31 / datasets.py:142-154 (names, edges), main.py:119-141
+    (export permutation, permuted names and re-indexed edges): the oracle's restatement (oracle/spec.py) and the
+    product's tables (metro_pose3d_amd/joints.py) against what the reference's code computed."""
+    from metro_pose3d_amd.joints import skeleton
+    from oracle.spec import export_permutation, head_joint_info, output_joint_info
+    t = {k.split('/')[-1]: ref[k] for k in ref.files if k.startswith(f'joints/{dataset}/')}
+    head, out = head_joint_info(dataset), output_joint_info(dataset)
+    assert [n.encode() for n in head.names] == list(t['head_names'])
+    assert [tuple(e) for e in head.edges] == [tuple(e) for e in t['head_edges'].tolist()]
+    assert head.mirror_mapping == t['mirror'].tolist()
+    assert export_permutation(dataset) == t['permutation'].tolist()
+    assert [n.encode() for n in out.names] == list(t['out_names'])
+    assert [tuple(e) for e in out.edges] == [tuple(e) for e in t['out_edges'].tolist()]
+    sk = skeleton(dataset)
+    assert sk.n_head == len(t['head_names']) and sk.n_out == len(t['out_names'])
+    assert list(sk.names_bytes()) == list(t['out_names'])
+    assert np.array_equal(sk.edges_array(), t['out_edges']) and sk.edges_array().dtype == np.int64
+    assert list(sk.permutation) == t['permutation'].tolist()
+    assert list(sk.head_mirror) == t['mirror'].tolist()
+    assert [tuple(e) for e in sk.head_edges] == [tuple(e) for e in t['head_edges'].tolist()]
