@@ -25,6 +25,8 @@ import os
 import sys
 import warnings
 
+sys.dont_write_bytecode = True      # /root/reference is read-only for this repo: importing from it must not leave __pycache__ there
+
 import numpy as np
 import scipy
 import scipy.optimize
