@@ -57,6 +57,48 @@ def load_bone_solver():
     return ns['optimize_z_offset_by_bones_single']
 
 
+def load_functions(relpath, names, ns):
+    """The named top-level functions of a reference module whose imports (TensorFlow, matplotlib) cannot run here."""
+    path = os.path.join(REF, relpath)
+    tree = ast.parse(open(path).read())
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(f.name for f in fns) == sorted(names), (relpath, names)
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, 'exec'), ns)
+    return ns
+
+
+def reference_eval_numbers(procrustes_module_fn, rng):
+    """build_eval_metrics (main.py:339-359) from the reference's own numpy pieces: tfu3d.root_relative (:23-25),
+    util3d.rigid_align / rigid_align_many (:139-171, the body of the py_func, run here with an explicit validity mask),
+    eval/analysis.get_pck / get_auc (:8-13).  Only the TF glue between them (tf.norm, reduce_mean_masked) is numpy here."""
+    import logging
+    import types
+    ns = {'np': np, 'logging': logging,
+          'eval': types.SimpleNamespace(procrustes=types.SimpleNamespace(procrustes=procrustes_module_fn))}
+    load_functions('src/util3d.py', ['rigid_align', 'rigid_align_many'], ns)
+    load_functions('src/tfu3d.py', ['root_relative'], ns)
+    load_functions('src/eval/analysis.py', ['get_pck', 'get_auc'], ns)
+    n, nj = 40, 17
+    true = (rng.standard_normal((n, nj, 3)) * 250).astype(np.float32)
+    pred = (true + rng.standard_normal((n, nj, 3)) * rng.uniform(20, 160, (n, 1, 1))).astype(np.float32)
+    valid = rng.uniform(size=(n, nj)) < 0.8
+    valid[:, -1] = True
+    valid[:4] = True
+    for i in range(n):                                   # >= 4 valid joints per pose (a well-posed alignment)
+        valid[i, rng.permutation(nj - 1)[:4]] = True
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        aligned = ns['rigid_align_many'](pred, true, joint_validity_mask=valid, scale_align=True).astype(np.float32)
+    dist = np.linalg.norm(ns['root_relative'](pred - true), axis=-1)
+    dist_pa = np.linalg.norm(ns['root_relative'](aligned - true), axis=-1)
+    rel = dist / np.float32(150)
+    per_joint = lambda f: np.array([f(rel[valid[:, j], j]) for j in range(nj)])
+    return {'met/true': true, 'met/pred': pred, 'met/valid': valid, 'met/aligned': aligned, 'met/dist': dist, 'met/dist_procrustes': dist_pa,
+            'met/mean_error': np.mean(dist[valid]), 'met/mean_error_procrustes': np.mean(dist_pa[valid]),
+            'met/mean_pck': ns['get_pck'](rel[valid]), 'met/mean_auc': ns['get_auc'](rel[valid]),
+            'met/pck': per_joint(ns['get_pck']), 'met/auc': per_joint(ns['get_auc'])}
+
+
 def reference_joint_tables():
     """{dataset: dict of arrays} computed by the reference's JointInfo / permute_joints (main.py:119-141)."""
     import itertools
@@ -154,6 +196,7 @@ def main():
         z_true = np.array([solve(x[i], delta_z[i], bones[i], H36M_EDGES) for i in range(m)])
     out.update({'bl/coords01': c01, 'bl/inv_intrinsics': inv_k, 'bl/stride': np.int32(stride), 'bl/x': x, 'bl/delta_z': delta_z, 'bl/edges': np.array(H36M_EDGES, np.int32), 'bl/target_mean': target_mean,
                 'bl/target_per_pose': bones, 'bl/z_mean_targets': z_mean, 'bl/z_per_pose_targets': z_true})
+    out.update(reference_eval_numbers(procrustes, rng))
     for ds, tab in reference_joint_tables().items():
         for k, v in tab.items():
             out[f'joints/{ds}/{k}'] = v

@@ -45,6 +45,27 @@ def test_oracle_metrics_use_the_reference_alignment(ref):
     assert np.abs(m['dist_procrustes'] - want).max() < 1e-4
 
 
+MET_KEYS = ('mean_error', 'mean_error_procrustes', 'mean_pck', 'mean_auc', 'pck', 'auc')
+
+
+def check_masked_metrics(got, ref, tol_dist, rtol):
+    """build_eval_metrics (main.py:339-359) with a validity mask, against the numbers the reference's own
+    rigid_align_many / root_relative / get_pck / get_auc produced (tests/golden/make_ref_fixtures.py)."""
+    valid = ref['met/valid']
+    for k in ('dist', 'dist_procrustes'):
+        g = got[k].cpu().numpy() if hasattr(got[k], 'cpu') else got[k]
+        assert np.abs(g - ref['met/' + k])[valid].max() < tol_dist, k
+    for k in MET_KEYS:
+        want = ref['met/' + k]
+        assert np.allclose(np.asarray(got[k], np.float64), want, rtol=rtol, atol=0), (k, got[k], want)
+
+
+def test_oracle_masked_metrics_match_reference(ref):
+    # the py_func hands float32 arrays to procrustes, so the reference aligns in float32; the oracle (and the device
+    # kernel) align in float64: they agree to float32 rounding of ~200 mm distances
+    check_masked_metrics(OM.eval_metrics(ref['met/pred'], ref['met/true'], ref['met/valid']), ref, 1e-3, 2e-6)
+
+
 def test_oracle_bone_length_solve_matches_reference(ref):
     """reference bone_length_based_backproj.py:38-62: scipy LM with the reference's (inexact) Jacobian."""
     x, dz, edges = ref['bl/x'], ref['bl/delta_z'], [tuple(e) for e in ref['bl/edges']]
@@ -81,6 +102,15 @@ def test_hip_metrics_match_reference_alignment(cuda, ref):
     want = np.linalg.norm(rr(aligned - true), axis=-1)
     assert np.abs(got['dist_procrustes'].cpu().numpy() - want).max() < 2e-3
     assert abs(got['mean_error_procrustes'] - want.mean()) < 1e-4 * want.mean()
+
+
+@pytest.mark.gpu
+def test_hip_masked_metrics_match_reference(cuda, ref):
+    import torch
+    from metro_pose3d_amd.metrics import eval_metrics
+    got = eval_metrics(torch.from_numpy(ref['met/pred']).to(cuda), torch.from_numpy(ref['met/true']).to(cuda),
+                       torch.from_numpy(ref['met/valid']).to(cuda))
+    check_masked_metrics(got, ref, 2e-3, 1e-5)
 
 
 @pytest.mark.gpu
