@@ -165,7 +165,7 @@ __global__ __launch_bounds__(c64::NT) void conv3x3_c64_kernel(C64Args a) {
             const int idx = tid + r * NT;
             const int prow = idx >> 3, ch = idx & 7;
             const uint4 v = *reinterpret_cast<const uint4*>(ol + prow * OUT_ROW + ch * 16);
-            *reinterpret_cast<uint4*>(a.out + (size_t)(m0 + prow) * C + ch * 8) = v;
+            store_out16<1>(a.out + (size_t)(m0 + prow) * C + ch * 8, v);
         }
     }
 }

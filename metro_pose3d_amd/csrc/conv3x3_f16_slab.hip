@@ -332,7 +332,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
         if (m >= a.m_total || co >= a.c_out) continue;
         const uint4 v = *reinterpret_cast<const uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16);
         if (co + 8 <= a.c_out) {
-            *reinterpret_cast<uint4*>(out + (size_t)m * a.c_out + co) = v;
+            store_out16<2>(out + (size_t)m * a.c_out + co, v);
         } else {
             const half8_t x = *reinterpret_cast<const half8_t*>(&v);
 #pragma unroll

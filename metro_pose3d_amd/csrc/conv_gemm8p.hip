@@ -316,7 +316,7 @@ __global__ __launch_bounds__(g8::NT) void conv_gemm8p_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[e] = x[e] + r[e];    // fp16 Add, like the reference graph
         }
-        *reinterpret_cast<uint4*>(o_ptr + (size_t)m * o_c + co) = v;
+        store_out16<2>(o_ptr + (size_t)m * o_c + co, v);
     }
 }
 

@@ -535,7 +535,7 @@ __device__ __forceinline__ void conv_dma_body(
 #ifdef METRO_DBG_SKIP_STORE
             if (a.m_total < 0)
 #endif
-            *reinterpret_cast<uint4*>(outh + (size_t)m * o_c + co) = v;
+            store_out16<2>(outh + (size_t)m * o_c + co, v);
             if constexpr (FUSE2) *reinterpret_cast<uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16) = v;
         } else {
             // ragged channel tail (c_out % 8 != 0 never carries a residual: see conv_f16_dma_supported)

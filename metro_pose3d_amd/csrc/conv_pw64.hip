@@ -304,7 +304,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = x[e] + rr[e];       // fp16 Add, like the reference graph
             }
-            if (m < a.m_total) *reinterpret_cast<uint4*>(a.out + (size_t)m * ldo + ch * 8) = v;
+            if (m < a.m_total) store_out16<1>(a.out + (size_t)m * ldo + ch * 8, v);
             if constexpr (MODE2 == 2) {
                 // next unit's pre-activation (fp16 BN + ReLU) goes back into the tile for the second GEMM
                 const half8_t z = {};

@@ -44,6 +44,21 @@ inline int tuning_knob(const char* name, int dflt) {
 #endif
 }
 
+// 16-byte activation store of an epilogue.  METRO_NT_STORES (A/B builds only) marks them non-temporal:
+//   1 = the streaming kernels whose outputs exceed the L2 (stem, conv_pw64, conv3x3_c64), 2 = every conv kernel.
+typedef unsigned int metro_u32x4 __attribute__((ext_vector_type(4)));
+template <int LEVEL = 1>
+__device__ __forceinline__ void store_out16(void* p, uint4 v) {
+#if defined(METRO_NT_STORES)
+    if constexpr (METRO_NT_STORES >= LEVEL) {
+        metro_u32x4 w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<metro_u32x4*>(p));
+        return;
+    }
+#endif
+    *reinterpret_cast<uint4*>(p) = v;
+}
+
 // ---- per-device one-time kernel setup -----------------------------------------------------------------------
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the occupancy query act on the CURRENT device's copy of a
 // kernel: a process that drives several GPUs (inference.py caches one Engine per device) must do them once per

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
                     }
                 }
             }
-            *reinterpret_cast<half8_t*>(a.out + (((size_t)img * ps + py0 + ppy) * ps + px0 + ppx) * 64 + c8 * 8) = best;
+            store_out16<1>(a.out + (((size_t)img * ps + py0 + ppy) * ps + px0 + ppx) * 64 + c8 * 8, *reinterpret_cast<const uint4*>(&best));
         }
         if (p + G >= a.n_patches) break;
         buf = buf + 1 == NBUF ? 0 : buf + 1;
