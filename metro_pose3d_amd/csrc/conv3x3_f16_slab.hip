@@ -47,33 +47,59 @@ __device__ __forceinline__ void slab_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// WM: 32-row cout tiles per wave (TM = WAVES_M*WM*32); pixels: TN = 256 = WAVES_N * WN * 32
+// WM: 32-row cout tiles per wave (TM = WAVES_M*WM*32); pixels: TN = WAVES_N * WN * 32 (256 or 512)
 // TPS: taps per K step.  1 = one (chunk, tap) per barrier; 3 = one kernel ROW (3 taps) per barrier for the
 // 64-cout tiles, whose 8 MFMAs per wave per tap are too few to amortise the barrier + fragment-read latency.
-template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int SLAB_ROWS_, int SLAB_BUFS_ = 2, int TPS_ = 1>
+// KC: input channels per chunk (slab and weight rows are KC*2 bytes).  64 for the 256-pixel tiles; the 512-pixel
+// tiles take 32 so that two slabs (2 x 40 KiB) and a deeper weight ring fit next to each other.
+// WS: weight ring depth (W(q + WS - 1) is issued during step q).
+// Why 512-pixel tiles: a tile streams its cout-slice of ALL weights (TM x 9 C_in) once, whatever its pixel count, so
+// the bytes a layer pulls from L2 into LDS are  tiles x (TM x 9 C_in x 2  +  slab);  block4's conv2 at batch 256 moved
+// 1.58 GB that way in 260 us (6.1 TB/s, the rate every DMA-fed kernel here settles at) -- twice the pixels per tile
+// halve the weight stream.
+template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int SLAB_ROWS_, int SLAB_BUFS_ = 2, int TPS_ = 1, int KC_ = 64, int WS_ = 3>
 struct SlabCfg {
     static constexpr int TPS = TPS_;
+    static constexpr int KC = KC_;
+    static constexpr int NKK = KC / 16;                      // MFMA k-steps per tap
+    static constexpr int ROW_BYTES = KC * 2;
+    static constexpr int RPI = 1024 / ROW_BYTES;             // LDS rows per DMA instruction (64 lanes x 16 B)
     static constexpr int SLAB_BUFS = SLAB_BUFS_;             // 1: single-chunk layers (c_in == 64): half the LDS, 2 blocks/CU
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, WM = WM_, WN = WN_;
     static constexpr int NW = WAVES_M * WAVES_N, NT = 64 * NW;
     static constexpr int TM = WAVES_M * WM * 32, TN = WAVES_N * WN * 32;
-    static constexpr int SLAB_ROWS = SLAB_ROWS_;             // padded to a multiple of 8*NW
-    static constexpr int SI = SLAB_ROWS / (8 * NW);          // slab DMA instructions per wave per chunk
-    static constexpr int WI = TM / (8 * NW);                 // weight DMA instructions per wave per step
-    static constexpr int SLAB_BYTES = SLAB_ROWS * 128;
+    static constexpr int SLAB_ROWS = SLAB_ROWS_;             // padded to a multiple of RPI*NW
+    static constexpr int SI = SLAB_ROWS / (RPI * NW);        // slab DMA instructions per wave per chunk
+    static constexpr int WI = TM / (RPI * NW);               // weight DMA instructions per wave per tap
+    static constexpr int SLAB_BYTES = SLAB_ROWS * ROW_BYTES;
     static constexpr int ZERO_OFF = SLAB_BUFS * SLAB_BYTES;  // 256-byte zero area behind the slab(s)
     static constexpr int W_OFF = ZERO_OFF + 256;
-    static constexpr int W_STAGE_BYTES = TPS * TM * 128;
-    static constexpr int W_STAGES = 3;
+    static constexpr int W_STAGE_BYTES = TPS * TM * ROW_BYTES;
+    static constexpr int W_STAGES = WS_;
+    static constexpr int NSTEPS = 9 / TPS;                   // steps per chunk
     static constexpr int RAW_BYTES = W_OFF + W_STAGES * W_STAGE_BYTES;
     static constexpr int OUT_ROW_BYTES = TM * 2 + 16;
     static constexpr int OUT_BYTES = TN * OUT_ROW_BYTES;
     static constexpr int LDS_BYTES = RAW_BYTES > OUT_BYTES ? RAW_BYTES : OUT_BYTES;
-    static_assert(TN == 256, "slab kernel tiles 256 pixels");
+    static_assert(TN == 256 || TN == 512, "slab kernel tiles 256 or 512 pixels");
+    static_assert(KC == 64 || KC == 32, "64 or 32 channels per chunk");
     static_assert(TPS == 1 || TPS == 3, "one tap or one kernel row per step");
-    static_assert(SLAB_ROWS % (8 * NW) == 0 && TM % (8 * NW) == 0, "loader mismatch");
+    static_assert(SLAB_ROWS % (RPI * NW) == 0 && TM % (RPI * NW) == 0, "loader mismatch");
+    static_assert(W_STAGES >= 3 && W_STAGES - 2 <= NSTEPS - 1, "ring depth");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    // swizzle of the 16-byte chunk index inside a row (conflict-free ds_read_b128 for 32 consecutive rows at any
+    // alignment: the 16 rows one LDS cycle serves cover the 256-byte bank span exactly once)
+    __device__ static __forceinline__ int swz(int row) { return KC == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
     // the epilogue tile overlays slabs + zero area + weight ring (all idle by then)
 };
+
+template <int I, int N, class F>
+__device__ __forceinline__ void slab_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        slab_static_for<I + 1, N>(f);
+    }
+}
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
@@ -102,8 +128,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
 
     const int c_in = a.c_in;
     const int k_total = 9 * c_in;
-    const int kc = (c_in + 63) / 64;
-    const int nq = kc * 9;                         // steps
+    const int kc = c_in / Cfg::KC;                 // chunks (c_in % 64 == 0: launcher)
     const int hw = a.h_out * a.w_out;
     const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page_slab);
     const unsigned smem_base = (unsigned)(size_t)(lds_void3_t*)smem;
@@ -112,32 +137,33 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
     if (tid < 16) reinterpret_cast<uint4*>(smem + Cfg::ZERO_OFF)[tid] = make_uint4(0, 0, 0, 0);
 
     // ---- DMA source coordinates -------------------------------------------------------------
-    const int lrow = lane >> 3, lch = lane & 7;
-    // slab rows: instruction i of this wave fills slab rows (i*NW + wave)*8 + lrow
+    constexpr int RPI = Cfg::RPI, CPR = Cfg::ROW_BYTES / 16;    // rows per DMA instruction, 16-byte chunks per row
+    const int lrow = lane / CPR, lch = lane % CPR;
+    // slab rows: instruction i of this wave fills slab rows (i*NW + wave)*RPI + lrow
     const half_t* ssrc[Cfg::SI];
     int skoff[Cfg::SI];
     bool svalid[Cfg::SI];
 #pragma unroll
     for (int i = 0; i < Cfg::SI; ++i) {
-        const int srow = (i * NW + wave) * 8 + lrow;
+        const int srow = (i * NW + wave) * RPI + lrow;
         const int g = m0 - halo + srow;              // flattened pixel index
         svalid[i] = g >= 0 && g < a.m_total;
         ssrc[i] = in + (size_t)(svalid[i] ? g : 0) * c_in;
-        skoff[i] = (lch ^ ((srow >> 1) & 7)) * 8;
+        skoff[i] = (lch ^ Cfg::swz(srow)) * 8;
     }
     const half_t* wsrc[Cfg::WI];
     int wkoff[Cfg::WI];
     bool wvalid[Cfg::WI];
 #pragma unroll
     for (int i = 0; i < Cfg::WI; ++i) {
-        const int row = (i * NW + wave) * 8 + lrow;
+        const int row = (i * NW + wave) * RPI + lrow;
         const int co = n0 + row;
         wvalid[i] = co < a.c_out;
         wsrc[i] = w + (size_t)(wvalid[i] ? co : 0) * k_total;
-        wkoff[i] = (lch ^ ((row >> 1) & 7)) * 8;
+        wkoff[i] = (lch ^ Cfg::swz(row)) * 8;
     }
 
-    // running DMA pointers (c_in % 64 == 0 is required by the launcher): the slab advances 64
+    // running DMA pointers (c_in % 64 == 0 is required by the launcher): the slab advances KC
     // channels per chunk; a weight row advances c_in per tap and wraps to the next chunk after 9 taps
     const half_t* sptr[Cfg::SI];
 #pragma unroll
@@ -146,27 +172,27 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
 #pragma unroll
     for (int i = 0; i < Cfg::WI; ++i) wptr[i] = wvalid[i] ? wsrc[i] + wkoff[i] : zero;
     const int w_tap_inc = c_in;                 // elements, tap t -> t+1
-    const int w_chunk_inc = 64 - 8 * c_in;      // elements, (c, 8) -> (c+1, 0)
+    const int w_chunk_inc = Cfg::KC - 8 * c_in; // elements, (c, 8) -> (c+1, 0)
 
     auto issue_slab_part = [&](int buf, int part, bool last_part) {     // next chunk -> slab buffer `buf`
-        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + buf * Cfg::SLAB_BYTES + wave * 8 * 128);
+        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + buf * Cfg::SLAB_BYTES + wave * 1024);
 #pragma unroll
         for (int i = 0; i < Cfg::SI; ++i) {
-            if ((i & 3) != part) continue;
-            slab_dma16(sptr[i], base + i * NW * 8 * 128);
-            sptr[i] += svalid[i] ? 64 : 0;
+            if (i % Cfg::NKK != part) continue;
+            slab_dma16(sptr[i], base + i * NW * 1024);
+            sptr[i] += svalid[i] ? Cfg::KC : 0;
         }
         (void)last_part;
     };
     // issues W of the step whose first tap is `t_issue` (TPS taps: t_issue .. t_issue+TPS-1), into ring slot `slot`;
-    // `tt` = which of those taps, `part` = quarter of its instructions; pointers advance after the last piece
+    // `tt` = which of those taps, `part` = which of its NKK pieces; pointers advance after the last piece
     auto issue_w_part = [&](int slot, int t_issue, int part, int tt = 0) {
         const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + Cfg::W_OFF + slot * Cfg::W_STAGE_BYTES +
-                                                             tt * Cfg::TM * 128 + wave * 8 * 128);
+                                                             tt * Cfg::TM * Cfg::ROW_BYTES + wave * 1024);
 #pragma unroll
         for (int i = 0; i < Cfg::WI; ++i) {
-            if ((i & 3) != part) continue;
-            slab_dma16(wptr[i] + (wvalid[i] ? tt * w_tap_inc : 0), base + i * NW * 8 * 128);
+            if (i % Cfg::NKK != part) continue;
+            slab_dma16(wptr[i] + (wvalid[i] ? tt * w_tap_inc : 0), base + i * NW * 1024);
             if (tt == Cfg::TPS - 1)
                 wptr[i] += wvalid[i] ? (t_issue + Cfg::TPS == 9 ? w_chunk_inc + (Cfg::TPS - 1) * w_tap_inc : Cfg::TPS * w_tap_inc) : 0;
         }
@@ -174,20 +200,36 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
 
     // ---- per-lane tap offsets into the slab (byte offset of the row, or the zero area) ---------
     const int frag_row = lane & 31, frag_half = lane >> 5;
-    int boff[Cfg::WN][9];
+    // TN == 256: the byte offset of every (pixel tile, tap) row in registers (-1 = outside the image).
+    // TN == 512: four pixel tiles per wave would need 36 such registers next to 128 accumulators; there each pixel
+    // tile keeps the offset of its centre row and a 9-bit validity mask, the tap displacement is a scalar.
+    constexpr bool TABLE = Cfg::TN == 256;
+    int boff[TABLE ? Cfg::WN : 1][9];
+    int bbase[Cfg::WN];
+    unsigned bmask[Cfg::WN];
 #pragma unroll
     for (int j = 0; j < Cfg::WN; ++j) {
         const int t = (wave_n * Cfg::WN + j) * 32 + frag_row;        // tile-local pixel
         const int m = m0 + t;
         const int rem = m % hw;
         const int h = rem / a.w_out, x = rem - h * a.w_out;
+        bbase[j] = (halo + t) * Cfg::ROW_BYTES;
+        bmask[j] = 0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dr = (tap / 3 - 1) * a.dil, ds = (tap % 3 - 1) * a.dil;
             const bool ok = m < a.m_total && (unsigned)(h + dr) < (unsigned)a.h_out &&
                             (unsigned)(x + ds) < (unsigned)a.w_out;
-            boff[j][tap] = ok ? (halo + t + dr * a.w_out + ds) * 128 : -1;
+            if constexpr (TABLE) boff[j][tap] = ok ? (halo + t + dr * a.w_out + ds) * Cfg::ROW_BYTES : -1;
+            bmask[j] |= ok ? 1u << tap : 0u;
         }
+    }
+
+    unsigned arow[Cfg::WM];                                     // weight fragment rows (lane constants)
+#pragma unroll
+    for (int i = 0; i < Cfg::WM; ++i) {
+        const int row = (wave_m * Cfg::WM + i) * 32 + frag_row;
+        arow[i] = row * Cfg::ROW_BYTES + ((frag_half ^ Cfg::swz(row)) << 4);
     }
 
     floatx16 acc[Cfg::WM][Cfg::WN];
@@ -198,103 +240,98 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // ---- prologue: slab(0), W(0), W(1) ---------------------------------------------------------
+    // ---- prologue: slab(0), W(0) .. W(WS-2) --------------------------------------------------------
+    constexpr int WS = Cfg::W_STAGES, NSTEPS = Cfg::NSTEPS, NKK = Cfg::NKK;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) issue_slab_part(0, p, false);
+    for (int p = 0; p < NKK; ++p) issue_slab_part(0, p, false);
 #pragma unroll
-    for (int tt = 0; tt < Cfg::TPS; ++tt)
+    for (int st = 0; st < WS - 1; ++st)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) issue_w_part(0, 0, p, tt);
+        for (int tt = 0; tt < Cfg::TPS; ++tt)
 #pragma unroll
-    for (int tt = 0; tt < Cfg::TPS; ++tt)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) issue_w_part(1, Cfg::TPS, p, tt);
+            for (int p = 0; p < NKK; ++p) issue_w_part(st, st * Cfg::TPS, p, tt);
     __syncthreads();   // zero area visible (plain ds_write above); DMA unaffected (asm, uncounted)
 
-    // One (chunk, tap) step.  TAP, the ring slot and what gets issued are compile-time, so each
-    // step is straight-line code: 16 ds_read_b128 + 16 MFMA + its share of the DMA issue.
+    // One step = TPS taps of one chunk.  The taps, what gets issued and the wait count are compile-time, so each
+    // step is straight-line code: ds_read_b128 + MFMA + its share of the DMA issue.  The ring slot is a constant
+    // for the 3-deep ring (9 taps = 3 turns), a rotating scalar for deeper ones.
     auto step = [&](auto tap_c, auto issue_slab_c, auto issue_w_c, auto wait_c, int slab_buf, int wslot) {
         constexpr int TAP0 = decltype(tap_c)::value;             // first tap of the step
         slab_wait_barrier<decltype(wait_c)::value>();
-        const char* wl = smem + Cfg::W_OFF + wslot * Cfg::W_STAGE_BYTES;
-        const char* sl = smem + slab_buf * Cfg::SLAB_BYTES;
-        const char* zl = smem + Cfg::ZERO_OFF;
-        const int islot = wslot == 0 ? 2 : wslot - 1;          // slot of step q+2 == slot of step q-1
+        const unsigned wl = Cfg::W_OFF + wslot * Cfg::W_STAGE_BYTES;
+        const unsigned sl = slab_buf * Cfg::SLAB_BYTES;
+        const int islot = wslot == 0 ? WS - 1 : wslot - 1;     // slot of step q+WS-1 == slot of step q-1
 #pragma unroll
         for (int tt = 0; tt < Cfg::TPS; ++tt) {
+            // LDS byte address of k-chunk `frag_half` of every fragment row of this tap; k-step kk is the same address
+            // with bit 5.. flipped (chunk = 2 kk ^ frag_half, the swizzle is an XOR): one VALU op per read instead of
+            // the whole row / swizzle / validity computation
+            const int TAP = TAP0 + tt;                          // (constant after unrolling)
+            unsigned pa[Cfg::WM], pb[Cfg::WN];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int i = 0; i < Cfg::WM; ++i) pa[i] = wl + tt * Cfg::TM * Cfg::ROW_BYTES + arow[i];
+#pragma unroll
+            for (int j = 0; j < Cfg::WN; ++j) {
+                int bo;
+                bool ok;
+                if constexpr (TABLE) {
+                    bo = boff[j][TAP];
+                    ok = bo >= 0;
+                } else {
+                    const int toff = __builtin_amdgcn_readfirstlane((((TAP / 3 - 1) * a.w_out + (TAP % 3 - 1)) * a.dil) * Cfg::ROW_BYTES);
+                    bo = bbase[j] + toff;
+                    ok = (bmask[j] >> TAP) & 1u;
+                }
+                pb[j] = ok ? sl + bo + ((frag_half ^ Cfg::swz(bo / Cfg::ROW_BYTES)) << 4) : (unsigned)Cfg::ZERO_OFF;
+            }
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
                 half8_t af[Cfg::WM], bf[Cfg::WN];
-                const int chunk = kk * 2 + frag_half;
 #pragma unroll
-                for (int i = 0; i < Cfg::WM; ++i) {
-                    const int row = (wave_m * Cfg::WM + i) * 32 + frag_row;
-                    af[i] = *reinterpret_cast<const half8_t*>(wl + tt * Cfg::TM * 128 + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-                }
+                for (int i = 0; i < Cfg::WM; ++i) af[i] = *reinterpret_cast<const half8_t*>(smem + (pa[i] ^ (kk << 5)));
 #pragma unroll
-                for (int j = 0; j < Cfg::WN; ++j) {
-                    const int bo = boff[j][TAP0 + tt];
-                    const char* p = bo >= 0 ? sl + bo + ((chunk ^ ((bo >> 8) & 7)) << 4) : zl;
-                    bf[j] = *reinterpret_cast<const half8_t*>(p);
-                }
-#ifdef METRO_SETPRIO
-                __builtin_amdgcn_s_setprio(1);
-#endif
+                for (int j = 0; j < Cfg::WN; ++j) bf[j] = *reinterpret_cast<const half8_t*>(smem + (pb[j] ^ (kk << 5)));
 #pragma unroll
                 for (int i = 0; i < Cfg::WM; ++i)
 #pragma unroll
                     for (int j = 0; j < Cfg::WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-#ifdef METRO_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 if constexpr (decltype(issue_slab_c)::value) {
-                    if (tt == 0) issue_slab_part(slab_buf ^ 1, kk, kk == 3);
+                    if (tt == 0) issue_slab_part(slab_buf ^ 1, kk, kk == NKK - 1);
                 }
-                if constexpr (decltype(issue_w_c)::value) issue_w_part(islot, (TAP0 + 2 * Cfg::TPS) % 9, kk, tt);
+                if constexpr (decltype(issue_w_c)::value) issue_w_part(islot, (TAP0 + (WS - 1) * Cfg::TPS) % 9, kk, tt);
             }
         }
     };
-    using T = std::true_type;
-    using F = std::false_type;
-    auto I = [](auto v) { return v; };
     constexpr int WSI = Cfg::WI * Cfg::TPS;        // weight DMA instructions per wave per step
-    // a whole chunk: 9 taps in 9 / TPS steps, slots cycle 0,1,2 (every chunk starts on slot 0)
+    // DMA instructions that may still be in flight at the top of step j of a chunk = those issued behind W(this
+    // step): W of the next WS-2 steps, plus the next chunk's slab while its issue step (j = 0) is among the last WS-2
+    int ring = 0;                                   // slot of the chunk's first step (deep rings)
+    auto slot_of = [&](int j) {
+        if constexpr (WS == 3) return j % 3;        // 9 taps (3 rows) = whole turns: every chunk starts on slot 0
+        else return (ring + j) % WS;
+    };
+    auto advance_ring = [&]() {
+        if constexpr (WS != 3) ring = (ring + NSTEPS) % WS;
+    };
     auto chunk_main = [&](int slab_buf) {       // not the last chunk: slab(c+1) during the first step, W always
-        if constexpr (Cfg::TPS == 3) {
-            step(std::integral_constant<int, 0>{}, T{}, T{}, std::integral_constant<int, WSI>{}, slab_buf, 0);
-            step(std::integral_constant<int, 3>{}, F{}, T{}, std::integral_constant<int, WSI + Cfg::SI>{}, slab_buf, 1);
-            step(std::integral_constant<int, 6>{}, F{}, T{}, std::integral_constant<int, WSI>{}, slab_buf, 2);
-        } else {
-        step(std::integral_constant<int, 0>{}, T{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
-        step(std::integral_constant<int, 1>{}, F{}, T{}, std::integral_constant<int, Cfg::WI + Cfg::SI>{}, slab_buf, 1);
-        step(std::integral_constant<int, 2>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
-        step(std::integral_constant<int, 3>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
-        step(std::integral_constant<int, 4>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
-        step(std::integral_constant<int, 5>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
-        step(std::integral_constant<int, 6>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
-        step(std::integral_constant<int, 7>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
-        step(std::integral_constant<int, 8>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
-        }
+        slab_static_for<0, NSTEPS>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int wait = (WS - 2) * WSI + ((j >= 1 && j <= WS - 2) ? Cfg::SI : 0);
+            step(std::integral_constant<int, j * Cfg::TPS>{}, std::integral_constant<bool, j == 0>{}, std::true_type{},
+                 std::integral_constant<int, wait>{}, slab_buf, slot_of(j));
+        });
+        advance_ring();
     };
-    auto chunk_last = [&](int slab_buf) {       // last chunk: no slab, W stops two steps before the end
-        if constexpr (Cfg::TPS == 3) {
-            step(std::integral_constant<int, 0>{}, F{}, T{}, std::integral_constant<int, WSI>{}, slab_buf, 0);
-            step(std::integral_constant<int, 3>{}, F{}, F{}, std::integral_constant<int, WSI>{}, slab_buf, 1);
-            step(std::integral_constant<int, 6>{}, F{}, F{}, std::integral_constant<int, 0>{}, slab_buf, 2);
-        } else {
-        step(std::integral_constant<int, 0>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
-        step(std::integral_constant<int, 1>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
-        step(std::integral_constant<int, 2>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
-        step(std::integral_constant<int, 3>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
-        step(std::integral_constant<int, 4>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
-        step(std::integral_constant<int, 5>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 2);
-        step(std::integral_constant<int, 6>{}, F{}, T{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 0);
-        step(std::integral_constant<int, 7>{}, F{}, F{}, std::integral_constant<int, Cfg::WI>{}, slab_buf, 1);
-        step(std::integral_constant<int, 8>{}, F{}, F{}, std::integral_constant<int, 0>{}, slab_buf, 2);
-        }
+    auto chunk_last = [&](int slab_buf) {       // last chunk: no slab, W stops WS-1 steps before the end
+        slab_static_for<0, NSTEPS>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int left = NSTEPS - 1 - j;
+            constexpr int wait = (left < WS - 2 ? left : WS - 2) * WSI;
+            step(std::integral_constant<int, j * Cfg::TPS>{}, std::false_type{}, std::integral_constant<bool, (j + WS - 1 < NSTEPS)>{},
+                 std::integral_constant<int, wait>{}, slab_buf, slot_of(j));
+        });
     };
-    (void)I; (void)nq;
     for (int c = 0; c + 1 < kc; ++c) chunk_main(c & 1);      // (kc > 1 requires SLAB_BUFS == 2: launcher)
     chunk_last(Cfg::SLAB_BUFS == 2 ? (kc - 1) & 1 : 0);
 
@@ -356,7 +393,13 @@ static int launch_slab_cfg(const ConvArgs& a, const half_t* in, const half_t* w,
 }
 
 //                    WAVES_M WAVES_N WM WN slab rows        tile, LDS
-using Slab128r320 = SlabCfg<2, 4, 2, 2, 320>;   // 128 cout x 256 px, halo <= 32:  80 + 48 KiB
+#ifndef METRO_SLAB_WS128
+#define METRO_SLAB_WS128 3
+#endif
+#ifndef METRO_SLAB_WS512
+#define METRO_SLAB_WS512 4
+#endif
+using Slab128r320 = SlabCfg<2, 4, 2, 2, 320, 2, 1, 64, METRO_SLAB_WS128>;   // 128 cout x 256 px, halo <= 32:  80 + 48 KiB
 using Slab128r384 = SlabCfg<2, 4, 2, 2, 384>;   // halo <= 64:  96 + 48 KiB
 using Slab64r320 = SlabCfg<1, 8, 2, 1, 320>;    //  64 cout x 256 px
 using Slab64r384 = SlabCfg<1, 8, 2, 1, 384>;
@@ -364,6 +407,7 @@ using Slab64r512 = SlabCfg<1, 8, 2, 1, 512>;    // halo <= 128: 128 + 24 KiB
 using Slab64r320t3 = SlabCfg<1, 8, 2, 1, 320, 2, 3>;   // one kernel row per step: 80 + 72 KiB
 using Slab64r384b1 = SlabCfg<1, 8, 2, 1, 384, 1>;  // single chunk (c_in == 64), halo <= 64: 48 + 24 KiB -> 2 blocks / CU
 using Slab64r320b1 = SlabCfg<1, 8, 2, 1, 320, 1>;
+using Slab128p512 = SlabCfg<2, 4, 2, 4, 640, 2, 1, 32, METRO_SLAB_WS512>;   // 128 cout x 512 px, 32-channel chunks, halo <= 64: 80 + 32 KiB (epilogue tile 136 KiB)
 
 bool conv3x3_slab_supported(const MetroConvDesc& d) {
     static const int enabled = tuning_knob("METRO_CONV_SLAB", 1);
@@ -401,6 +445,10 @@ int launch_conv3x3_slab(const MetroConvDesc& d, const void* in_, const void* w_,
         if (halo <= 64) return launch_slab_cfg<Slab64r384>(a, in, w, bias, out, halo, stream);
         return launch_slab_cfg<Slab64r512>(a, in, w, bias, out, halo, stream);
     }
+    // 512-pixel tiles (half the weight stream per pixel) once they still give every CU two tiles
+    static const int min512 = tuning_knob("METRO_SLAB512_MIN_TILES", 512);
+    const long blocks512 = (long)((d.c_out + 127) / 128) * ((a.m_total + 511) / 512);
+    if (blocks512 >= min512) return launch_slab_cfg<Slab128p512>(a, in, w, bias, out, halo, stream);
     if (halo <= 32) return launch_slab_cfg<Slab128r320>(a, in, w, bias, out, halo, stream);
     return launch_slab_cfg<Slab128r384>(a, in, w, bias, out, halo, stream);
 }

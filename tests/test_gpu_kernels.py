@@ -92,6 +92,33 @@ def test_conv_f16(lib, cuda, case, variant):
     assert np.abs(got - ref).max() <= tol, (np.abs(got - ref).max(), scale)
 
 
+# (name, n, side, c_in, c_out, rate): 3x3 layers with enough 512-pixel tiles (>= 512 of 128 cout x 512 px) for the
+# 512-pixel slab configuration -- the stride-16 net's conv2 shapes at batch 256, a half-image-per-tile map, a ragged
+# last tile.  The fp64 reference is computed for a sample of images (first / last, both halves of a tile pair).
+P512_CASES = [('block3_b256', 256, 16, 256, 256, 1), ('block4_b256_rate2', 256, 16, 512, 512, 2), ('block2_b256', 256, 32, 128, 128, 1),
+              ('ragged_515', 515, 16, 64, 256, 1), ('cout_tail_320', 400, 16, 64, 320, 1)]
+
+
+@pytest.mark.parametrize('case', P512_CASES, ids=[c[0] for c in P512_CASES])
+@pytest.mark.parametrize('relu', [False, True], ids=['plain', 'relu'])
+def test_conv3x3_slab_512px_tiles(lib, cuda, case, relu):
+    name, n, side, c_in, c_out, rate = case
+    rng = np.random.default_rng(zlib.crc32(f'p512/{name}/{relu}'.encode()))
+    x16 = rng.standard_normal((n, side, side, c_in)).astype(np.float16)
+    w16 = (rng.standard_normal((c_out, 3, 3, c_in)) * np.sqrt(2.0 / (9 * c_in))).astype(np.float16)
+    b = (rng.standard_normal(c_out) * 0.1).astype(np.float32)
+    d = H.conv_desc(n, side, c_in, side, c_out, 3, 1, rate, rate, relu=relu, in_dtype=_lib.METRO_F16)
+    got = H.run_conv_f16(lib, cuda, d, x16, w16, b).astype(np.float64)
+    assert np.isfinite(got).all()
+    sample = sorted({0, 1, 2, n // 2, n // 2 + 1, n - 2, n - 1})
+    ref = H.ref_conv_nhwc(x16[sample], w16, b, 1, rate, rate, side, relu=relu).numpy()
+    tol = 2e-3 * np.abs(ref).max()
+    assert np.abs(got[sample] - ref).max() <= tol, (np.abs(got[sample] - ref).max(), np.abs(ref).max())
+    # race screen: the same launch again under a different schedule gives the same bits
+    again = H.run_conv_f16(lib, cuda, d, x16, w16, b).astype(np.float64)
+    assert np.array_equal(got, again)
+
+
 @pytest.mark.parametrize('shape', [(2, 8, 64, 128), (5, 16, 64, 256), (3, 11, 64, 256), (5, 16, 128, 512)],
                          ids=['ring', 'pw64', 'pw64_ragged', 'pw128'])
 @pytest.mark.parametrize('res_stride,res_offset', [(2, 0), (2, 1)])
