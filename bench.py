@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg (0 = skip)')
     ap.add_argument('--cpu-crops', type=int, default=8)
     ap.add_argument('--layer-report', type=str, default=None, help='write the per-layer table to this file')
+    ap.add_argument('--diag-zero-data', action='store_true',
+                    help='DIAGNOSTIC, not a result: all-zero weights and crops (same instructions, no data toggling) -- how far '
+                         'the step is from the power budget that sets the clock (MI355X_MICROARCH.md, DVFS give-back)')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the accuracy / parity-mode / batch-256 legs (profiling runs)')
     return ap.parse_args()
@@ -230,10 +233,14 @@ def main():
     spec = ModelSpec(args.arch, args.stride, dataset)
     params = synth.make_params(spec.arch, spec.n_head_channels, spec.base_width, seed=0,
                                logit_gain=synth.logit_gain_for(spec.arch, spec.stride))
+    if args.diag_zero_data:
+        params = {k: np.zeros_like(v) for k, v in params.items()}
     eng = Engine(spec, params, args.precision, max_batch=args.batch, device=device)
     b = args.batch
     # each rank gets ITS OWN crops (seeded by rank): weak scaling, global batch = b * world
     images_np = synth.make_images(b, spec.proc_side, seed=1234 + rank)
+    if args.diag_zero_data:
+        images_np = np.zeros_like(images_np)
     images = torch.from_numpy(images_np).to(device)
     jout = spec.skeleton.n_out
     local = torch.empty((b, jout, 3), dtype=torch.float32, device=device)
@@ -301,7 +308,8 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'f16': 'f16', 'f32': 'f32 storage, f64 accumulate', 'f64': 'f64'}[args.precision],
-            'data': 'synthetic (seeded random weights + uniform [0,1) crops; no released weights offline)',
+            'data': 'ALL-ZERO weights and crops: DIAGNOSTIC RUN, NOT A RESULT' if args.diag_zero_data else
+                    'synthetic (seeded random weights + uniform [0,1) crops; no released weights offline)',
             'config': {'workload': f'RN{args.arch}-s{args.stride}-J{spec.skeleton.n_head} {dataset}, '
                                    f'batch {b}/GPU, 256x256x3 fp32 NHWC in HBM -> poses [B,{jout},3] mm',
                        'global_batch': b * world, 'per_gpu_batch': b,
@@ -344,6 +352,22 @@ def main():
         out['parity_mode'] = {'precision': 'f64 (fp64 MFMA, fp64 storage)', 'crops_per_s': round(b * psteps / (pms * 1e-3), 1),
                               'ms_per_step': round(pms / psteps, 3), 'steps': psteps}
         del eng64
+        if not args.diag_zero_data:
+            # DVFS diagnostic (not a result): the SAME launches on all-zero weights and crops.  The chip clocks to its
+            # power budget (MI355X_MICROARCH.md, "DVFS give-back"); the ratio says how much of the step time is the
+            # clock the data's switching activity allows rather than stall cycles a better schedule could remove.
+            engz = Engine(spec, {k_: np.zeros_like(v_) for k_, v_ in params.items()}, 'f16', max_batch=b, device=device)
+            imgz = torch.zeros_like(images)
+            for _ in range(3):
+                engz.forward(imgz, out=local)
+            zs = 20
+            _, zms, zper = timed_steps(lambda: engz.forward(imgz, out=local), zs, device, 1, dist)
+            out['power_diagnostic'] = {
+                'zero_data_gpu_ms_per_step_median': round(float(np.median(zper)), 4), 'steps': zs,
+                'ratio_to_timed_run': round(float(np.median(zper)) / float(np.median(per_step)), 3),
+                'note': 'same binary, same launches, all-zero weights and crops: not a throughput claim; the MFMA-bound '
+                        'launches run ~20 % faster on zeros (clock set by the power budget)'}
+            del engz, imgz
         if b != 256 and (args.arch, args.stride) == (50, 16):
             b2 = 256
             eng2 = Engine(spec, params, 'f16', max_batch=b2, device=device)

@@ -240,8 +240,41 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // ---- prologue: slab(0), W(0) .. W(WS-2) --------------------------------------------------------
     constexpr int WS = Cfg::W_STAGES, NSTEPS = Cfg::NSTEPS, NKK = Cfg::NKK;
+    constexpr int WSI = Cfg::WI * Cfg::TPS;        // weight DMA instructions per wave per step
+    int ring = 0;                                   // slot of the chunk's first step (deep rings)
+    auto slot_of = [&](int j) {
+        if constexpr (WS == 3) return j % 3;        // 9 taps (3 rows) = whole turns: every chunk starts on slot 0
+        else return (ring + j) % WS;
+    };
+    auto advance_ring = [&]() {
+        if constexpr (WS != 3) ring = (ring + NSTEPS) % WS;
+    };
+    // LDS byte addresses of k-chunk `frag_half` of the fragment rows of tap TAP (weights in ring slot `wslot`, tap
+    // `tt` of its step; pixels in slab `slab_buf`); k-step kk is the same address with bit 5.. flipped (chunk =
+    // 2 kk ^ frag_half and the swizzle is an XOR): one VALU op per read
+    auto frag_addr = [&](int TAP, int tt, int slab_buf, int wslot, unsigned (&pa)[Cfg::WM], unsigned (&pb)[Cfg::WN]) {
+        const unsigned wl = Cfg::W_OFF + wslot * Cfg::W_STAGE_BYTES;
+        const unsigned sl = slab_buf * Cfg::SLAB_BYTES;
+#pragma unroll
+        for (int i = 0; i < Cfg::WM; ++i) pa[i] = wl + tt * Cfg::TM * Cfg::ROW_BYTES + arow[i];
+#pragma unroll
+        for (int j = 0; j < Cfg::WN; ++j) {
+            int bo;
+            bool ok;
+            if constexpr (TABLE) {
+                bo = boff[j][TAP];
+                ok = bo >= 0;
+            } else {
+                const int toff = __builtin_amdgcn_readfirstlane((((TAP / 3 - 1) * a.w_out + (TAP % 3 - 1)) * a.dil) * Cfg::ROW_BYTES);
+                bo = bbase[j] + toff;
+                ok = (bmask[j] >> TAP) & 1u;
+            }
+            pb[j] = ok ? sl + bo + ((frag_half ^ Cfg::swz(bo / Cfg::ROW_BYTES)) << 4) : (unsigned)Cfg::ZERO_OFF;
+        }
+    };
+
+    // ---- prologue: slab(0), W(0) .. W(WS-2) --------------------------------------------------------
 #pragma unroll
     for (int p = 0; p < NKK; ++p) issue_slab_part(0, p, false);
 #pragma unroll
@@ -258,32 +291,11 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
     auto step = [&](auto tap_c, auto issue_slab_c, auto issue_w_c, auto wait_c, int slab_buf, int wslot) {
         constexpr int TAP0 = decltype(tap_c)::value;             // first tap of the step
         slab_wait_barrier<decltype(wait_c)::value>();
-        const unsigned wl = Cfg::W_OFF + wslot * Cfg::W_STAGE_BYTES;
-        const unsigned sl = slab_buf * Cfg::SLAB_BYTES;
         const int islot = wslot == 0 ? WS - 1 : wslot - 1;     // slot of step q+WS-1 == slot of step q-1
 #pragma unroll
         for (int tt = 0; tt < Cfg::TPS; ++tt) {
-            // LDS byte address of k-chunk `frag_half` of every fragment row of this tap; k-step kk is the same address
-            // with bit 5.. flipped (chunk = 2 kk ^ frag_half, the swizzle is an XOR): one VALU op per read instead of
-            // the whole row / swizzle / validity computation
-            const int TAP = TAP0 + tt;                          // (constant after unrolling)
             unsigned pa[Cfg::WM], pb[Cfg::WN];
-#pragma unroll
-            for (int i = 0; i < Cfg::WM; ++i) pa[i] = wl + tt * Cfg::TM * Cfg::ROW_BYTES + arow[i];
-#pragma unroll
-            for (int j = 0; j < Cfg::WN; ++j) {
-                int bo;
-                bool ok;
-                if constexpr (TABLE) {
-                    bo = boff[j][TAP];
-                    ok = bo >= 0;
-                } else {
-                    const int toff = __builtin_amdgcn_readfirstlane((((TAP / 3 - 1) * a.w_out + (TAP % 3 - 1)) * a.dil) * Cfg::ROW_BYTES);
-                    bo = bbase[j] + toff;
-                    ok = (bmask[j] >> TAP) & 1u;
-                }
-                pb[j] = ok ? sl + bo + ((frag_half ^ Cfg::swz(bo / Cfg::ROW_BYTES)) << 4) : (unsigned)Cfg::ZERO_OFF;
-            }
+            frag_addr(TAP0 + tt, tt, slab_buf, wslot, pa, pb);
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
                 half8_t af[Cfg::WM], bf[Cfg::WN];
@@ -302,17 +314,6 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
                 if constexpr (decltype(issue_w_c)::value) issue_w_part(islot, (TAP0 + (WS - 1) * Cfg::TPS) % 9, kk, tt);
             }
         }
-    };
-    constexpr int WSI = Cfg::WI * Cfg::TPS;        // weight DMA instructions per wave per step
-    // DMA instructions that may still be in flight at the top of step j of a chunk = those issued behind W(this
-    // step): W of the next WS-2 steps, plus the next chunk's slab while its issue step (j = 0) is among the last WS-2
-    int ring = 0;                                   // slot of the chunk's first step (deep rings)
-    auto slot_of = [&](int j) {
-        if constexpr (WS == 3) return j % 3;        // 9 taps (3 rows) = whole turns: every chunk starts on slot 0
-        else return (ring + j) % WS;
-    };
-    auto advance_ring = [&]() {
-        if constexpr (WS != 3) ring = (ring + NSTEPS) % WS;
     };
     auto chunk_main = [&](int slab_buf) {       // not the last chunk: slab(c+1) during the first step, W always
         slab_static_for<0, NSTEPS>([&](auto jc) {
@@ -445,8 +446,9 @@ int launch_conv3x3_slab(const MetroConvDesc& d, const void* in_, const void* w_,
         if (halo <= 64) return launch_slab_cfg<Slab64r384>(a, in, w, bias, out, halo, stream);
         return launch_slab_cfg<Slab64r512>(a, in, w, bias, out, halo, stream);
     }
-    // 512-pixel tiles (half the weight stream per pixel) once they still give every CU two tiles
-    static const int min512 = tuning_knob("METRO_SLAB512_MIN_TILES", 512);
+    // 512-pixel tiles (half the weight stream per pixel) once they still give every CU a tile (A/B: 256 beats 512 as the
+    // threshold at batch 128 and 256)
+    static const int min512 = tuning_knob("METRO_SLAB512_MIN_TILES", 256);
     const long blocks512 = (long)((d.c_out + 127) / 128) * ((a.m_total + 511) / 512);
     if (blocks512 >= min512) return launch_slab_cfg<Slab128p512>(a, in, w, bias, out, halo, stream);
     if (halo <= 32) return launch_slab_cfg<Slab128r320>(a, in, w, bias, out, halo, stream);

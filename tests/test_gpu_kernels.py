@@ -92,7 +92,7 @@ def test_conv_f16(lib, cuda, case, variant):
     assert np.abs(got - ref).max() <= tol, (np.abs(got - ref).max(), scale)
 
 
-# (name, n, side, c_in, c_out, rate): 3x3 layers with enough 512-pixel tiles (>= 512 of 128 cout x 512 px) for the
+# (name, n, side, c_in, c_out, rate): 3x3 layers with enough 512-pixel tiles (>= 256 of 128 cout x 512 px) for the
 # 512-pixel slab configuration -- the stride-16 net's conv2 shapes at batch 256, a half-image-per-tile map, a ragged
 # last tile.  The fp64 reference is computed for a sample of images (first / last, both halves of a tile pair).
 P512_CASES = [('block3_b256', 256, 16, 256, 256, 1), ('block4_b256_rate2', 256, 16, 512, 512, 2), ('block2_b256', 256, 32, 128, 128, 1),
