@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define METRO_ABI_VERSION 3
+#define METRO_ABI_VERSION 4
 
 typedef enum MetroStatus {
     METRO_OK = 0,
@@ -196,6 +196,16 @@ int  metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d
 int  metro_conv_f16_gemm8p(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                            const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
                            int32_t split, void* d_out2, void* stream);
+/* conv2 (3x3, BN + ReLU folded) -> conv3 (1x1, bias) -> + shortcut of one bottleneck unit in ONE launch (reference
+ * resnet_v2.py:130-138): d2 = the 3x3 layer's descriptor, d3 = the 1x1 layer's (has_residual), for the 256-wide
+ * bottlenecks on 16x16 maps (block3 of the stride-16 / stride-32 nets: c 256 -> 256 -> 1024, rate 1).  d_t2 receives
+ * conv2's output (a real tensor, fp16 [n,16,16,256]); four workgroups per image hand their quarters of it to each other
+ * inside the launch through d_flags: uint32 [2 n], zero before the first call on it (the launch leaves it zero).
+ * The grid is persistent and fully resident; the launch returns METRO_ERR_INVALID_ARG for any other pair of layers.
+ * EXPERIMENT: measured slower than the two separate launches (measured dead ends); metro_forward does not use it. */
+int  metro_conv_f16_conv2_conv3(const MetroConvDesc* d2, const void* d_t1, const void* d_w2, const float* d_bias2, void* d_t2,
+                                const MetroConvDesc* d3, const void* d_w3, const float* d_bias3, const void* d_residual,
+                                void* d_out, void* d_flags, void* stream);
 /* Stem 7x7/2 convolution (+bias) and zero-padded 3x3/2 max-pool in one launch (reference resnet_v2.py:219-224,
  * resnet_utils.py:138-185).  d_prepped = metro_prep_input_f16 output [n,side+6,side+8,4] fp16, d_w packed
  * [64][7][8][4] fp16, d_out fp16 [n,side/4,side/4,64].  side % 32 == 0. */

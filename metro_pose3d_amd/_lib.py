@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('METRO_HIP_LIB') or os.path.join(HERE, 'libmetro_hip.so')   # override: timing experiments
 
 METRO_MAX_JOINTS = 64
-ABI_VERSION = 3          # include/metro_hip.h METRO_ABI_VERSION
+ABI_VERSION = 4          # include/metro_hip.h METRO_ABI_VERSION
 METRO_PREC_F16, METRO_PREC_F32, METRO_PREC_F64 = 0, 1, 2
 METRO_F16, METRO_F32, METRO_F64 = 0, 1, 2
 PARAM_CONV_W, PARAM_BIAS, PARAM_PRO_SCALE, PARAM_PRO_SHIFT = 0, 1, 2, 3
@@ -77,6 +77,7 @@ SIGNATURES = {
     'metro_conv_f64acc': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f16_pair': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
     'metro_conv_f16_gemm8p': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
+    'metro_conv_f16_conv2_conv3': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P]),
     'metro_conv_f16_next': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     'metro_stem_pool_f16': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     'metro_stem_pool_f32in': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),

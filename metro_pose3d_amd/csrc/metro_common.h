@@ -209,6 +209,11 @@ bool conv3x3_c64_supported(const MetroConvDesc& d);
 int launch_conv3x3_c64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out, hipStream_t stream);
 // 3x3 stride-1 convs with tap reuse from an LDS-resident activation slab
 bool conv3x3_slab_supported(const MetroConvDesc& d);
+// conv2 + conv3 + shortcut of a 256-wide bottleneck on 16x16 maps in one launch (conv3x3_f16_slab.hip)
+bool conv3x3_conv1x1_fused_supported(const MetroConvDesc& d2, const MetroConvDesc& d3);
+int launch_conv3x3_conv1x1_fused(const MetroConvDesc& d2, const void* t1, const void* w2, const float* b2, void* t2,
+                                 const MetroConvDesc& d3, const void* w3, const float* b3, const void* res, void* out,
+                                 unsigned* flags, hipStream_t stream);
 int launch_conv3x3_slab(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out,
                         hipStream_t stream);
 int launch_conv_f64acc(const MetroConvDesc& d, const void* in, const double* w, const double* bias,

@@ -796,6 +796,20 @@ int metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d_
                                static_cast<hipStream_t>(stream), nullptr, &f2);
 }
 
+int metro_conv_f16_conv2_conv3(const MetroConvDesc* d2, const void* d_t1, const void* d_w2, const float* d_bias2, void* d_t2,
+                               const MetroConvDesc* d3, const void* d_w3, const float* d_bias3, const void* d_residual,
+                               void* d_out, void* d_flags, void* stream) {
+    METRO_CHECK_ARG(d2 && d3, "conv_f16_conv2_conv3: NULL descriptor");
+    int st = validate_conv_desc(d2);
+    if (st) return st;
+    st = validate_conv_desc(d3);
+    if (st) return st;
+    METRO_CHECK_ARG(d_t1 && d_w2 && d_bias2 && d_t2 && d_w3 && d_bias3 && d_residual && d_out && d_flags,
+                    "conv_f16_conv2_conv3: NULL tensor pointer");
+    return launch_conv3x3_conv1x1_fused(*d2, d_t1, d_w2, d_bias2, d_t2, *d3, d_w3, d_bias3, d_residual, d_out,
+                                        static_cast<unsigned*>(d_flags), static_cast<hipStream_t>(stream));
+}
+
 int metro_conv_f16_gemm8p(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                           const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
                           int32_t split, void* d_out2, void* stream) {
