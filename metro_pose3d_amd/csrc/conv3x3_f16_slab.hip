@@ -627,7 +627,10 @@ static int launch_slab_cfg(const ConvArgs& a, const half_t* in, const half_t* w,
 #endif
 using Slab128r320 = SlabCfg<2, 4, 2, 2, 320, 2, 1, 64, METRO_SLAB_WS128>;   // 128 cout x 256 px, halo <= 32:  80 + 48 KiB
 using Slab128r384 = SlabCfg<2, 4, 2, 2, 384>;   // halo <= 64:  96 + 48 KiB
-using Slab64r320 = SlabCfg<1, 8, 2, 1, 320>;    //  64 cout x 256 px
+#ifndef METRO_SLAB_WS64
+#define METRO_SLAB_WS64 3
+#endif
+using Slab64r320 = SlabCfg<1, 8, 2, 1, 320, 2, 1, 64, METRO_SLAB_WS64>;    //  64 cout x 256 px
 using Slab64r384 = SlabCfg<1, 8, 2, 1, 384>;
 using Slab64r512 = SlabCfg<1, 8, 2, 1, 512>;    // halo <= 128: 128 + 24 KiB
 using Slab64r320t3 = SlabCfg<1, 8, 2, 1, 320, 2, 3>;   // one kernel row per step: 80 + 72 KiB
