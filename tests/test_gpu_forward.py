@@ -182,6 +182,31 @@ def test_batch_independence_full_width_persistent_kernels(cuda):
     assert torch.equal(whole, parts)
 
 
+def test_large_batch_tile_shapes_agree_with_small_batches(cuda):
+    """From 128 crops per call on, the 3x3 layers with >= 256 tiles of 512 pixels switch to those tiles (32-channel chunks: a
+    different fp32 accumulation order), so a large batch is no longer BIT-identical to its halves; it must still be the same
+    tensor to within rounding flips at the first such layer (same inputs up to there), and the same poses to within the
+    distance of two fp16 realisations of one graph."""
+    from tests.test_f16_layerwise import compare_fp16
+    spec = ModelSpec(50, 16, 'h36m')
+    n = 130
+    params, images = _setup(spec, n, gain=synth.logit_gain_for(50, 16))
+    x = torch.from_numpy(images).to(cuda)
+    big = Engine(spec, params, 'f16', max_batch=n, device=cuda)
+    small = Engine(spec, params, 'f16', max_batch=n // 2, device=cuda)
+    names = [li.name.decode() for li in big.layer_infos()]
+    halves = lambda f: torch.cat([f(x[:n // 2]).clone(), f(x[n // 2:]).clone()])
+    i = names.index('block2/unit_1/conv2')
+    before = big.forward_upto(x, i - 1)
+    assert torch.equal(before, halves(lambda t: small.forward_upto(t, i - 1))), 'layers in front of the first 512-pixel-tile layer'
+    a = big.forward_upto(x, i).cpu().double().numpy()
+    b = halves(lambda t: small.forward_upto(t, i)).cpu().double().numpy()
+    assert not np.array_equal(a, b), 'expected the 512-pixel tiles at this batch (dispatch changed? update this test)'
+    compare_fp16(a, b, 'block2/unit_1/conv2, 512-pixel vs 256-pixel tiles')
+    pa, pb = big.forward(x).cpu().numpy(), halves(small.forward).cpu().numpy()
+    assert np.isfinite(pa).all() and np.abs(pa - pb).max() < 6.0 and np.abs(pa - pb).mean() < 0.6, (np.abs(pa - pb).max(), np.abs(pa - pb).mean())
+
+
 def test_two_devices_in_one_process(cuda):
     """One process may drive several GPUs (inference._engine_for caches one Engine per device): the per-kernel LDS
     opt-in and the persistent kernels' grid caps are per DEVICE (metro_common.h: PerDeviceInt), so the second device
