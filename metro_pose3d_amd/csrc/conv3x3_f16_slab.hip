@@ -1,20 +1,23 @@
 // 3x3 stride-1 (dilated) convolution with TAP REUSE: the activation slab of a pixel tile is staged
-// in LDS once per 64-channel chunk and all 9 taps are served from it.
+// in LDS once per channel chunk and all 9 taps are served from it.
 //
 // The generic implicit GEMM (conv_igemm_f16_dma.hip) re-fetches the 256-pixel activation tile for
 // every tap, so a 3x3 layer moves 9x its activations from L2 into LDS; PMC showed those layers
-// bound by L2->LDS delivery (~9 TB/s of a ~16 TB/s LDS-DMA ceiling), not by MFMA.  Here:
-//   * a tile is 256 CONSECUTIVE pixels in (n,h,w) order (whole rows / whole images: consecutive
-//     in NHWC memory too).  Its slab is the flattened pixel range [m0 - halo, m0 + 256 + halo),
-//     halo = dil*W + dil: one contiguous range -> plain row-by-row LDS-DMA, 1/9 of the traffic;
+// bound by L2->LDS delivery, not by MFMA.  Here:
+//   * a tile is 256 or 512 CONSECUTIVE pixels in (n,h,w) order (whole rows / whole images: consecutive
+//     in NHWC memory too).  Its slab is the flattened pixel range [m0 - halo, m0 + TN + halo),
+//     halo = dil*W: one contiguous range -> plain row-by-row LDS-DMA, 1/9 of the traffic;
 //   * tap (dr,ds) of tile pixel t reads slab row halo + t + (dr*W + ds)*dil, or a ZERO row when the
 //     tap leaves the image (TF SAME zero padding, reference resnet_utils.py:120-123); the per-lane
-//     row offsets of all 9 taps are computed once;
-//   * weights stream per (chunk, tap) step through a 3-deep LDS-DMA ring; the next chunk's slab is
-//     issued during the tap-0 step into the other slab buffer.  One raw s_barrier per step; waits
-//     are counted (s_waitcnt vmcnt(N)) over the merged in-order DMA stream.
+//     row offsets (256-pixel tiles) or centre offset + validity mask (512) are computed once;
+//   * weights stream per step (one tap, or one kernel row of three taps, of one chunk) through a 3- or
+//     4-deep LDS-DMA ring; the next chunk's slab is issued during the chunk's first step into the other
+//     slab buffer.  One raw s_barrier per step; waits are counted (s_waitcnt vmcnt(N)) over the merged
+//     in-order DMA stream.  SlabCfg holds the tile shape, chunk width, ring depth and taps per step.
 // Covers the reference's conv2 call sites with stride 1: resnet_v2.py:130-132 via
 // resnet_utils.conv2d_same (SAME padding, rate r).  Post-conv BN+ReLU folded (bias + ReLU).
+// Below the tile: an EXPERIMENTAL launch that chains conv3 + shortcut behind it for block3 (four
+// workgroups per image, in-launch hand-off), measured slower than two launches and not dispatched.
 #include <cstdlib>
 #include <type_traits>
 
