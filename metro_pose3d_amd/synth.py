@@ -51,7 +51,9 @@ def block_layout(arch: int, base_width: int) -> List[Tuple[int, int]]:
 
 
 def make_params(arch: int, n_head_channels: int, base_width: int = 64, seed: int = 0,
-                logit_gain: float = 1.0) -> Dict[str, np.ndarray]:
+                logit_gain: float = 1.0, res_gain: float = RES_GAIN) -> Dict[str, np.ndarray]:
+    """res_gain: std multiplier of every conv3 (RES_GAIN in all fixtures and in the bench; 1.0 = the undamped He
+    initialisation, used by the parity tests as a second, harsher fp16 regime)."""
     root = f'MainPart/resnet_v2_{arch}'
     p: Dict[str, np.ndarray] = {}
 
@@ -83,7 +85,7 @@ def make_params(arch: int, n_head_channels: int, base_width: int = 64, seed: int
             bn(s + '/conv1/BatchNorm', cb)
             conv(s + '/conv2', 3, 3, cb, cb, bias=False)
             bn(s + '/conv2/BatchNorm', cb)
-            conv(s + '/conv3', 1, 1, cb, cout, bias=True, gain=RES_GAIN)
+            conv(s + '/conv3', 1, 1, cb, cout, bias=True, gain=res_gain)
             cin = cout
     bn(root + '/postnorm', cin)
     conv(root + '/logits', 1, 1, cin, n_head_channels, bias=True, gain=logit_gain)
