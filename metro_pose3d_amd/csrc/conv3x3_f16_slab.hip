@@ -60,9 +60,8 @@ __device__ __forceinline__ void slab_wait_barrier() {
 // the bytes a layer pulls from L2 into LDS are  tiles x (TM x 9 C_in x 2  +  slab);  block4's conv2 at batch 256 moved
 // 1.58 GB that way in 260 us (6.1 TB/s, the rate every DMA-fed kernel here settles at) -- twice the pixels per tile
 // halve the weight stream.
-template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int SLAB_ROWS_, int SLAB_BUFS_ = 2, int TPS_ = 1, int KC_ = 64, int WS_ = 3, int STRIDE_ = 1>
+template <int WAVES_M_, int WAVES_N_, int WM_, int WN_, int SLAB_ROWS_, int SLAB_BUFS_ = 2, int TPS_ = 1, int KC_ = 64, int WS_ = 3>
 struct SlabCfg {
-    static constexpr int STRIDE = STRIDE_;                   // 2: the stride-2 conv2 of a block's last unit (128-pixel tiles inside one image)
     static constexpr int TPS = TPS_;
     static constexpr int KC = KC_;
     static constexpr int NKK = KC / 16;                      // MFMA k-steps per tap
@@ -85,8 +84,7 @@ struct SlabCfg {
     static constexpr int OUT_ROW_BYTES = TM * 2 + 16;
     static constexpr int OUT_BYTES = TN * OUT_ROW_BYTES;
     static constexpr int LDS_BYTES = RAW_BYTES > OUT_BYTES ? RAW_BYTES : OUT_BYTES;
-    static_assert(TN == 256 || TN == 512 || (TN == 128 && STRIDE == 2), "slab kernel tiles 256 or 512 pixels (128 at stride 2)");
-    static_assert(STRIDE == 1 || STRIDE == 2, "stride");
+    static_assert(TN == 256 || TN == 512, "slab kernel tiles 256 or 512 pixels");
     static_assert(KC == 64 || KC == 32, "64 or 32 channels per chunk");
     static_assert(TPS == 1 || TPS == 3, "one tap or one kernel row per step");
     static_assert(SLAB_ROWS % (RPI * NW) == 0 && TM % (RPI * NW) == 0, "loader mismatch");
@@ -134,15 +132,6 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
     if (tid < 16) reinterpret_cast<uint4*>(smem + Cfg::ZERO_OFF)[tid] = make_uint4(0, 0, 0, 0);
 
     // ---- DMA source coordinates -------------------------------------------------------------
-    // slab row 0 = flattened INPUT pixel slab_g0.  Stride 1: m0 - halo (input and output pixels coincide).  Stride 2 (the
-    // tile lies inside one image, TN % W_out == 0): the pixel left of the first tap of the tile's first output row, i.e.
-    // row 2 y0 - pad_top, column -pad_left; tap (r, s) of output (y, x) is slab row (2 (y - y0) + r) W_in + 2 x + s.
-    const int in_total = a.n * a.h_in * a.w_in;
-    int slab_g0 = m0 - halo;
-    if constexpr (Cfg::STRIDE == 2) {
-        const int img = m0 / hw, y0 = (m0 - img * hw) / a.w_out;
-        slab_g0 = img * a.h_in * a.w_in + (2 * y0 - a.pad_top) * a.w_in - a.pad_left;
-    }
     constexpr int RPI = Cfg::RPI, CPR = Cfg::ROW_BYTES / 16;    // rows per DMA instruction, 16-byte chunks per row
     const int lrow = lane / CPR, lch = lane % CPR;
     // slab rows: instruction i of this wave fills slab rows (i*NW + wave)*RPI + lrow
@@ -152,8 +141,8 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
 #pragma unroll
     for (int i = 0; i < Cfg::SI; ++i) {
         const int srow = (i * NW + wave) * RPI + lrow;
-        const int g = slab_g0 + srow;                // flattened input pixel index
-        svalid[i] = g >= 0 && g < in_total;
+        const int g = m0 - halo + srow;              // flattened pixel index
+        svalid[i] = g >= 0 && g < a.m_total;
         ssrc[i] = in + (size_t)(svalid[i] ? g : 0) * c_in;
         skoff[i] = (lch ^ Cfg::swz(srow)) * 8;
     }
@@ -209,7 +198,7 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
     // TN == 256: the byte offset of every (pixel tile, tap) row in registers (-1 = outside the image).
     // TN == 512: four pixel tiles per wave would need 36 such registers next to 128 accumulators; there each pixel
     // tile keeps the offset of its centre row and a 9-bit validity mask, the tap displacement is a scalar.
-    constexpr bool TABLE = Cfg::TN == 256 && Cfg::STRIDE == 1;
+    constexpr bool TABLE = Cfg::TN == 256;
     int boff[TABLE ? Cfg::WN : 1][9];
     int bbase[Cfg::WN];
     unsigned bmask[Cfg::WN];
@@ -219,18 +208,8 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
         const int m = m0 + t;
         const int rem = m % hw;
         const int h = rem / a.w_out, x = rem - h * a.w_out;
-        bmask[j] = 0;
-        if constexpr (Cfg::STRIDE == 2) {
-            const int y0 = ((m0 % hw) / a.w_out);
-            bbase[j] = (2 * (h - y0) * a.w_in + 2 * x) * Cfg::ROW_BYTES;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int iy = 2 * h - a.pad_top + (tap / 3) * a.dil, ix = 2 * x - a.pad_left + (tap % 3) * a.dil;
-                const bool ok = m < a.m_total && (unsigned)iy < (unsigned)a.h_in && (unsigned)ix < (unsigned)a.w_in;
-                bmask[j] |= ok ? 1u << tap : 0u;
-            }
-        } else {
         bbase[j] = (halo + t) * Cfg::ROW_BYTES;
+        bmask[j] = 0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dr = (tap / 3 - 1) * a.dil, ds = (tap % 3 - 1) * a.dil;
@@ -238,7 +217,6 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
                             (unsigned)(x + ds) < (unsigned)a.w_out;
             if constexpr (TABLE) boff[j][tap] = ok ? (halo + t + dr * a.w_out + ds) * Cfg::ROW_BYTES : -1;
             bmask[j] |= ok ? 1u << tap : 0u;
-        }
         }
     }
 
@@ -283,9 +261,7 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
                 bo = boff[j][TAP];
                 ok = bo >= 0;
             } else {
-                const int toff = __builtin_amdgcn_readfirstlane(
-                    Cfg::STRIDE == 2 ? (((TAP / 3) * a.w_in + (TAP % 3)) * a.dil) * Cfg::ROW_BYTES
-                                     : (((TAP / 3 - 1) * a.w_out + (TAP % 3 - 1)) * a.dil) * Cfg::ROW_BYTES);
+                const int toff = __builtin_amdgcn_readfirstlane((((TAP / 3 - 1) * a.w_out + (TAP % 3 - 1)) * a.dil) * Cfg::ROW_BYTES);
                 bo = bbase[j] + toff;
                 ok = (bmask[j] >> TAP) & 1u;
             }
@@ -602,7 +578,7 @@ __global__ __launch_bounds__(512) void conv3x3_conv1x1_fused_kernel(Conv23Args g
 
 bool conv3x3_conv1x1_fused_supported(const MetroConvDesc& d2, const MetroConvDesc& d3) {
     static const int enabled = tuning_knob("METRO_CONV23_FUSED", 1);
-    return enabled && d2.stride == 1 && conv3x3_slab_supported(d2) && d2.c_in == 256 && d2.c_out == 256 && d2.h_out == 16 && d2.w_out == 16 &&
+    return enabled && conv3x3_slab_supported(d2) && d2.c_in == 256 && d2.c_out == 256 && d2.h_out == 16 && d2.w_out == 16 &&
            d2.dilation == 1 && d2.relu && d3.kh == 1 && d3.kw == 1 && d3.stride == 1 && d3.c_in == 256 && d3.c_out == 1024 &&
            d3.n == d2.n && d3.h_in == 16 && d3.w_in == 16 && d3.h_out == 16 && d3.w_out == 16 && d3.in_pix_stride == 256 &&
            !d3.has_prologue && !d3.relu && d3.has_residual && d3.res_stride == 1 && d3.res_offset == 0 && d3.res_h == 16 &&
@@ -665,35 +641,13 @@ using Slab64r384b1 = SlabCfg<1, 8, 2, 1, 384, 1>;  // single chunk (c_in == 64),
 using Slab64r320b1 = SlabCfg<1, 8, 2, 1, 320, 1>;
 using Slab128p512 = SlabCfg<2, 4, 2, 4, 640, 2, 1, 32, METRO_SLAB_WS512>;   // 128 cout x 512 px, 32-channel chunks, halo <= 64: 80 + 32 KiB (epilogue tile 136 KiB)
 
-using Slab64s2 = SlabCfg<1, 4, 2, 1, 640, 2, 3, 32, 3, 2>;   // stride 2: 64 cout x 128 output px, four waves, 80 + 36 KiB
-
-// stride-2 conv2 of a block's last unit (resnet_v2.py:130-132 with stride 2: conv2d_same pads explicitly, or not at all
-// on top/left in the centered variant, resnet_utils.py:110-135): 128 consecutive output pixels of ONE image per tile,
-// their (2 R + 1) input rows as one contiguous slab
-static bool conv3x3_slab_stride2_supported(const MetroConvDesc& d) {
-    static const int enabled = tuning_knob("METRO_CONV_SLAB_S2", 1);
-    if (!enabled || d.dilation != 1 || d.pad_top < 0 || d.pad_top > 1 || d.pad_left < 0 || d.pad_left > 1) return false;
-    const int hw = d.h_out * d.w_out;
-    if (d.w_out > 128 || 128 % d.w_out != 0 || hw % 128 != 0) return false;
-    const int rows_out = 128 / d.w_out;
-    const int slab_rows = (2 * (rows_out - 1) + 2) * d.w_in + 2 * (d.w_out - 1) + 2 + 1;
-    if (slab_rows > Slab64s2::SLAB_ROWS) return false;
-    // measured (batch 64): 128 -> 128 on 32x32 -> 16x16 (256 tiles, one per CU) 20.5 -> 16.9 us; 64 -> 64 on 64x64 -> 32x32
-    // (512 tiles, one 116 KiB block per CU at a time) 20.8 -> 25.3 us: the generic ring kernel overlaps two or three smaller
-    // blocks per CU there.  So: only where every tile gets its own CU.
-    const long tiles = (long)d.n * hw / 128 * ((d.c_out + 63) / 64);
-    static const int max_tiles = tuning_knob("METRO_CONV_SLAB_S2_MAX_TILES", 256);
-    return d.c_in >= 128 && tiles <= max_tiles;
-}
-
 bool conv3x3_slab_supported(const MetroConvDesc& d) {
     static const int enabled = tuning_knob("METRO_CONV_SLAB", 1);
     if (!enabled) return false;
-    if (!(d.kh == 3 && d.kw == 3 && !d.has_prologue && !d.has_residual && d.out_dtype == METRO_F16 && d.in_dtype == METRO_F16 &&
-          d.in_pix_stride == d.c_in && d.c_in % 64 == 0 && d.c_out % 8 == 0))
-        return false;
-    if (d.stride == 2) return conv3x3_slab_stride2_supported(d);
-    if (!(d.stride == 1 && d.h_in == d.h_out && d.w_in == d.w_out && d.pad_top == d.dilation && d.pad_left == d.dilation))
+    if (!(d.kh == 3 && d.kw == 3 && d.stride == 1 && d.h_in == d.h_out && d.w_in == d.w_out &&
+          d.pad_top == d.dilation && d.pad_left == d.dilation && !d.has_prologue && !d.has_residual &&
+          d.out_dtype == METRO_F16 && d.in_dtype == METRO_F16 && d.in_pix_stride == d.c_in &&
+          d.c_in % 64 == 0 && d.c_out % 8 == 0))
         return false;
     // tiles are 256 consecutive pixels starting at column 0 (256 % W == 0): a tap (dr, ds<0) of a pixel
     // at x < dil is outside the image, so the slab needs dil*W rows of halo, not dil*W + dil
@@ -711,7 +665,6 @@ int launch_conv3x3_slab(const MetroConvDesc& d, const void* in_, const void* w_,
     const half_t* in = static_cast<const half_t*>(in_);
     const half_t* w = static_cast<const half_t*>(w_);
     half_t* out = static_cast<half_t*>(out_);
-    if (d.stride == 2) return launch_slab_cfg<Slab64s2>(a, in, w, bias, out, 0, stream);
     const int halo = d.dilation * d.w_out;
     // 64-cout tiles when 128-cout tiles would leave CUs without a block (256 CUs)
     const long blocks128 = (long)((d.c_out + 127) / 128) * ((a.m_total + 255) / 256);

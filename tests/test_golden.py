@@ -15,7 +15,7 @@ from tests import helpers as H
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'golden_poses_v1.npz')
 GOLD_F16 = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'golden_f16emu_v1.npz')
-F16_POSE_RATIO = 1.5     # f16 mode vs exact math: mean |d| at most this multiple of the fp16 oracle's own
+F16_POSE_RATIO = 2.0     # f16 mode vs exact math: mean |d| at most this multiple of the fp16 oracle's own
 F16_POSE_RATIO_MAX = 2.5 # ... and the maximum (a noisy statistic of 17-57 values per crop) within this factor
 
 

@@ -39,7 +39,7 @@ CONV_CASES = [
     ('3x3_s2_centered', 2, 32, 64, 64, 3, 2, 1, 0, 16),
     ('3x3_big', 4, 32, 128, 256, 3, 1, 1, 1, 32),
     # stride-2 conv2 of a block's last unit: the real shapes of block1 / block2 with both pad rules (explicit 1 / centered 0).
-    # 128 -> 128 with <= 256 tiles runs in the tap-reuse kernel (128-output-pixel tiles inside one image), 64 -> 64 in the ring
+    # (generic ring kernel: the tap-reuse kernel is stride 1 only)
     ('3x3_s2_slab_block1', 3, 64, 64, 64, 3, 2, 1, 1, 32),
     ('3x3_s2_slab_block1_centered', 3, 64, 64, 64, 3, 2, 1, 0, 32),
     ('3x3_s2_slab_block2', 5, 32, 128, 128, 3, 2, 1, 1, 16),
