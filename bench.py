@@ -200,6 +200,30 @@ def roofline_of(eng, images, gpu_ms_per_step: float, reps: int, layer_report=Non
             'algorithmic_gflop_per_forward': round(conv_flops / 1e9, 3)}
 
 
+def attach_traffic(roof: dict, batch: int) -> None:
+    """roofline.traffic from the newest committed profiles/*_pmc_traffic.json of this batch, if it was collected for the
+    kernel sources the library is built from (otherwise null + a note)."""
+    files = []
+    for f in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')):
+        with open(f) as fh:
+            t = json.load(fh)
+        if int(t.get('batch', 64)) == batch:
+            files.append((os.path.getmtime(f), f, t))
+    if not files:
+        return
+    _, path, t = sorted(files)[-1]
+    sha = kernels_sha16()
+    if t.get('kernels_sha16') == sha:
+        roof['traffic'] = t['conv_hbm_bytes_per_forward']
+        roof['traffic_note'] = (f'HBM bytes per forward summed over the {t["conv_launches"]} conv launches, '
+                                f'(2*FETCH_SIZE + WRITE_SIZE)*1024 from {os.path.basename(path)} '
+                                f'(rocprofv3 --pmc, separate passes, kernels {sha}; avg per launch '
+                                f'{t["conv_hbm_bytes_per_launch_avg"]:.3e} B)')
+    else:
+        roof['traffic_note'] = (f'{os.path.basename(path)} was collected for kernels {t.get("kernels_sha16")}, '
+                                f'the library is now built from {sha}: stale, not reported (re-run profiles/collect.sh)')
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -281,20 +305,7 @@ def main():
     # HBM traffic of the conv launches comes from a COMMITTED rocprofv3 PMC run of the same kernels (counters cannot be
     # collected from inside the process being profiled): profiles/*_pmc_traffic.json, valid only for the sources it names
     if rank == 0 and (args.arch, args.stride, dataset, b, args.precision) == (50, 16, 'h36m', 64, 'f16'):
-        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), key=os.path.getmtime)
-        sha = kernels_sha16()
-        if files:
-            with open(files[-1]) as f:
-                t = json.load(f)
-            if t.get('kernels_sha16') == sha:
-                roof['traffic'] = t['conv_hbm_bytes_per_forward']
-                roof['traffic_note'] = (f'HBM bytes per forward summed over the {t["conv_launches"]} conv launches, '
-                                        f'(2*FETCH_SIZE + WRITE_SIZE)*1024 from {os.path.basename(files[-1])} '
-                                        f'(rocprofv3 --pmc, separate passes, kernels {sha}; avg per launch '
-                                        f'{t["conv_hbm_bytes_per_launch_avg"]:.3e} B)')
-            else:
-                roof['traffic_note'] = (f'{os.path.basename(files[-1])} was collected for kernels {t.get("kernels_sha16")}, '
-                                        f'the library is now built from {sha}: stale, not reported (re-run profiles/collect.sh)')
+        attach_traffic(roof, 64)
 
     out = None
     if rank == 0:
@@ -378,6 +389,7 @@ def main():
             s2 = 10
             el2, gms2, per2 = timed_steps(lambda: eng2.forward(img2, out=out2), s2, device, 1, dist)
             roof2 = roofline_of(eng2, img2, gms2 / s2, reps=3)
+            attach_traffic(roof2, 256)
             out['b256'] = {'workload': f'RN{args.arch}-s{args.stride}-J{spec.skeleton.n_head} {dataset}, batch 256 on 1 GPU '
                                        '(the batch the north star quotes its roofline target on)',
                            'value': round(b2 * s2 / el2, 2), 'unit': 'crops/s', 'steps': s2, 'ms_per_step': round(el2 * 1e3 / s2, 4),

@@ -17,6 +17,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python profiles/pmc_table.py $out/pmc 1 > $out/${tag}_pmc_layers.tsv
 python profiles/pmc_traffic.py $out/${tag}_pmc_layers.tsv $tag > $out/${tag}_pmc_traffic.json
+# the same two passes at batch 256 (the `b256` sub-record of the bench line)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc256/$c -o $tag -- python bench.py --batch 256 --steps 2 --warmup 1 --cpu-seconds 0 --no-extras > $out/pmc256_$c.log 2>&1
+done
+python profiles/pmc_table.py $out/pmc256 1 > $out/${tag}_b256_pmc_layers.tsv
+python profiles/pmc_traffic.py $out/${tag}_b256_pmc_layers.tsv ${tag}_b256 256 > $out/${tag}_b256_pmc_traffic.json
 # matrix-pipe / wait counters per launch (one pass: 5 SQ + 1 GRBM slots)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $out/sq/a -o $tag -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extras > $out/pmc_sq.log 2>&1 || echo "SQ pass failed (see $out/pmc_sq.log)"
 python profiles/pmc_table.py $out/sq 1 > $out/${tag}_sq_layers.tsv || true
