@@ -24,7 +24,11 @@ One JSON line on stdout from rank 0, with
                   arithmetic model of the graph (oracle/f16emu.py) has itself;
   parity_mode  -- crops/s of the f64 parity mode on the same batch (outside the timed region);
   b256         -- (N = 1) the same workload at batch 256, the batch BASELINE.json's north star
-                  quotes its roofline target on: crops/s, ms/step and its own roofline object.
+                  quotes its roofline target on: crops/s, ms/step and its own roofline object;
+  c3_shard, c4_shard, c5_shard -- (N = 1) one GPU's shard of BASELINE.json configs[2..4] (RN50-s16-J19
+                  batch 512/8, RN101-s8-J19 batch 256/8, RN50-s4-J17 batch 128/8), each with its roofline;
+  boundary     -- (N = 1) 256 crops through `estimate_pose` itself (the drop-in call of reference
+                  inference.py:31-43, model file -> poses), Python overhead included.
 """
 from __future__ import annotations
 
@@ -70,12 +74,33 @@ def parse_args():
 
 
 def kernels_sha16() -> str:
-    """Hash of every source the library is built from: a committed PMC traffic file is only valid for these."""
+    """Hash of every source the library is built from (metro_pose3d_amd/build.py SOURCES + HEADERS, nothing else that may lie
+    in csrc/): a committed PMC traffic file is only valid for these."""
+    from metro_pose3d_amd.build import CSRC, HEADERS, SOURCES
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'metro_pose3d_amd', 'csrc', '*'))):
+    for f in sorted(os.path.normpath(os.path.join(CSRC, x)) for x in list(SOURCES) + list(HEADERS)):
         h.update(os.path.basename(f).encode())
         h.update(open(f, 'rb').read())
     return h.hexdigest()[:16]
+
+
+def workload_key(arch: int, stride: int, dataset: str, batch: int) -> str:
+    return f'rn{arch}-s{stride}-{dataset}-b{batch}'
+
+
+def host_cpu():
+    """(logical cores visible to this process, logical cores of the host, CPU model string)."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return avail, os.cpu_count() or avail, model
 
 
 def oracle_spec(spec):
@@ -90,7 +115,7 @@ def cpu_baseline(spec, params, seconds: float, crops: int):
     from oracle import forward as OF
     from metro_pose3d_amd import synth
     ospec = oracle_spec(spec)
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    avail, host_cores, cpu_model = host_cpu()
     images = synth.make_images(crops, spec.proc_side, seed=99)
     t_start = time.perf_counter()
     with torch.no_grad():
@@ -128,9 +153,12 @@ def cpu_baseline(spec, params, seconds: float, crops: int):
             if el >= seconds or done >= 64 * crops:
                 break
     return {'value': round(done / el, 3), 'unit': 'crops/s', 'cores': cores, 'kind': 'port',
+            'host_logical_cores': host_cores, 'host_cores_visible_to_this_process': avail, 'host_cpu_model': cpu_model,
+            'cores_note': '`cores` = the torch threads of the timed run (the fastest thread count tried); the host has '
+                          f'{host_cores} logical cores ({avail} visible to this process)',
             'one_thread_crops_per_s': round(one_thread, 3),
             'sample': f'{done} crops ({done // crops} passes of {crops}) of the same RN{spec.arch}-s{spec.stride} '
-                      f'graph in {el:.1f} s: oracle/forward.py, PyTorch-CPU fp32, {cores} threads (fastest of 8..{avail} on this host); '
+                      f'graph in {el:.1f} s: oracle/forward.py, PyTorch-CPU fp32, {cores} threads (fastest of 8..{avail} on this host: {cpu_model}); '
                       f'1 thread: {n1} single-crop passes; not TensorFlow (reference CPU path cannot run here)'}
 
 
@@ -200,28 +228,79 @@ def roofline_of(eng, images, gpu_ms_per_step: float, reps: int, layer_report=Non
             'algorithmic_gflop_per_forward': round(conv_flops / 1e9, 3)}
 
 
-def attach_traffic(roof: dict, batch: int) -> None:
-    """roofline.traffic from the newest committed profiles/*_pmc_traffic.json of this batch, if it was collected for the
-    kernel sources the library is built from (otherwise null + a note)."""
+def attach_traffic(roof: dict, workload) -> None:
+    """roofline.traffic from the committed profiles/*_pmc_traffic.json of this workload (a workload_key(), or a batch of the
+    default RN50-s16-h36m workload) that was collected for the kernel sources the library is built from; a file for other
+    sources is refused (traffic null + a note).  Selection is by content, never by file time (arbitrary after a checkout)."""
+    if isinstance(workload, int):
+        workload = workload_key(50, 16, 'h36m', workload)
     files = []
-    for f in glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')):
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
         with open(f) as fh:
             t = json.load(fh)
-        if int(t.get('batch', 64)) == batch:
-            files.append((os.path.getmtime(f), f, t))
+        if t.get('workload', workload_key(50, 16, 'h36m', int(t.get('batch', 64)))) == workload:
+            files.append((f, t))
     if not files:
         return
-    _, path, t = sorted(files)[-1]
     sha = kernels_sha16()
-    if t.get('kernels_sha16') == sha:
+    match = [(f, t) for f, t in files if t.get('kernels_sha16') == sha]
+    if match:
+        path, t = match[-1]                       # several files for the same sources: the last by name
         roof['traffic'] = t['conv_hbm_bytes_per_forward']
         roof['traffic_note'] = (f'HBM bytes per forward summed over the {t["conv_launches"]} conv launches, '
                                 f'(2*FETCH_SIZE + WRITE_SIZE)*1024 from {os.path.basename(path)} '
                                 f'(rocprofv3 --pmc, separate passes, kernels {sha}; avg per launch '
                                 f'{t["conv_hbm_bytes_per_launch_avg"]:.3e} B)')
     else:
+        path, t = files[-1]
         roof['traffic_note'] = (f'{os.path.basename(path)} was collected for kernels {t.get("kernels_sha16")}, '
                                 f'the library is now built from {sha}: stale, not reported (re-run profiles/collect.sh)')
+
+
+def side_workload(device, dist, arch, stride, dataset, batch, steps, warmup, what, seed=1234):
+    """One more workload on this GPU outside the main timed region (N = 1): its own engine, crops and roofline."""
+    from metro_pose3d_amd import ModelSpec, synth
+    from metro_pose3d_amd.engine import Engine
+    spec = ModelSpec(arch, stride, dataset)
+    params = synth.make_params(spec.arch, spec.n_head_channels, spec.base_width, seed=0,
+                               logit_gain=synth.logit_gain_for(spec.arch, spec.stride))
+    eng = Engine(spec, params, 'f16', max_batch=batch, device=device)
+    img = torch.from_numpy(synth.make_images(batch, spec.proc_side, seed=seed)).to(device)
+    out = torch.empty((batch, spec.skeleton.n_out, 3), dtype=torch.float32, device=device)
+    for _ in range(warmup):
+        eng.forward(img, out=out)
+    el, gms, per = timed_steps(lambda: eng.forward(img, out=out), steps, device, 1, dist)
+    roof = roofline_of(eng, img, gms / steps, reps=3)
+    attach_traffic(roof, workload_key(arch, stride, dataset, batch))
+    rec = {'workload': f'RN{arch}-s{stride}-J{spec.skeleton.n_head} {dataset}, batch {batch} on 1 GPU ({what})',
+           'value': round(batch * steps / el, 2), 'unit': 'crops/s', 'steps': steps, 'warmup': warmup,
+           'ms_per_step': round(el * 1e3 / steps, 4), 'gpu_ms_per_step_median': round(float(np.median(per)), 4),
+           'gflop_per_crop': round(eng.flops_per_image / 1e9, 3), 'finite': bool(torch.isfinite(out).all()), 'roofline': roof}
+    del eng, img, out
+    torch.cuda.empty_cache()
+    return rec
+
+
+def boundary_leg(device, dist, spec, params, batch, steps, warmup):
+    """`estimate_pose(images, model_path)` -- the drop-in call (reference inference.py:31-43) -- timed as a caller sees it:
+    model file on disk (loaded and planned once, cached), crops resident on the GPU, poses on the GPU."""
+    import tempfile
+    from metro_pose3d_amd import save_model, synth
+    from metro_pose3d_amd import inference as INF
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'model.npz')
+        save_model(path, spec, params)
+        img = torch.from_numpy(synth.make_images(batch, spec.proc_side, seed=1234)).to(device)
+        for _ in range(warmup):
+            poses, _, _ = INF.estimate_pose(img, path)
+        el, gms, per = timed_steps(lambda: INF.estimate_pose(img, path), steps, device, 1, dist)
+        ok = bool(torch.isfinite(poses).all())
+        INF._ENGINES.clear()
+    return {'call': f'metro_pose3d_amd.inference.estimate_pose(images[{batch},256,256,3] on the GPU, model_path) -> poses on the GPU',
+            'value': round(batch * steps / el, 2), 'unit': 'crops/s', 'steps': steps, 'ms_per_call': round(el * 1e3 / steps, 4),
+            'gpu_ms_per_call_median': round(float(np.median(per)), 4), 'finite': ok,
+            'note': 'one metro_forward(n = 256) per call (the engine is planned for the batch the call is given); includes the '
+                    'Python argument checks, output allocation and the names/edges arrays of every call'}
 
 
 def main():
@@ -304,8 +383,8 @@ def main():
 
     # HBM traffic of the conv launches comes from a COMMITTED rocprofv3 PMC run of the same kernels (counters cannot be
     # collected from inside the process being profiled): profiles/*_pmc_traffic.json, valid only for the sources it names
-    if rank == 0 and (args.arch, args.stride, dataset, b, args.precision) == (50, 16, 'h36m', 64, 'f16'):
-        attach_traffic(roof, 64)
+    if rank == 0 and args.precision == 'f16' and not args.diag_zero_data:
+        attach_traffic(roof, workload_key(args.arch, args.stride, dataset, b))
 
     out = None
     if rank == 0:
@@ -379,23 +458,14 @@ def main():
                 'note': 'same binary, same launches, all-zero weights and crops: not a throughput claim; the MFMA-bound '
                         'launches run ~20 % faster on zeros (clock set by the power budget)'}
             del engz, imgz
-        if b != 256 and (args.arch, args.stride) == (50, 16):
-            b2 = 256
-            eng2 = Engine(spec, params, 'f16', max_batch=b2, device=device)
-            img2 = torch.from_numpy(synth.make_images(b2, spec.proc_side, seed=1234)).to(device)
-            out2 = torch.empty((b2, jout, 3), dtype=torch.float32, device=device)
-            for _ in range(3):
-                eng2.forward(img2, out=out2)
-            s2 = 10
-            el2, gms2, per2 = timed_steps(lambda: eng2.forward(img2, out=out2), s2, device, 1, dist)
-            roof2 = roofline_of(eng2, img2, gms2 / s2, reps=3)
-            attach_traffic(roof2, 256)
-            out['b256'] = {'workload': f'RN{args.arch}-s{args.stride}-J{spec.skeleton.n_head} {dataset}, batch 256 on 1 GPU '
-                                       '(the batch the north star quotes its roofline target on)',
-                           'value': round(b2 * s2 / el2, 2), 'unit': 'crops/s', 'steps': s2, 'ms_per_step': round(el2 * 1e3 / s2, 4),
-                           'gpu_ms_per_step_median': round(float(np.median(per2)), 4),
-                           'finite': bool(torch.isfinite(out2).all()), 'roofline': roof2}
-            del eng2, img2
+        if b != 256 and (args.arch, args.stride, dataset) == (50, 16, 'h36m') and not args.diag_zero_data:
+            out['b256'] = side_workload(device, dist, 50, 16, 'h36m', 256, 10, 3,
+                                        'the batch the north star quotes its roofline target on')
+            # one GPU's shard of BASELINE.json configs[2..4] (the 8-GPU runs are the driver's; a shard is what a rank computes)
+            out['c3_shard'] = side_workload(device, dist, 50, 16, 'many19', 64, 20, 3, 'configs[2]: batch 512 sharded over 8 GPUs')
+            out['c4_shard'] = side_workload(device, dist, 101, 8, 'many19', 32, 10, 3, 'configs[3]: batch 256 sharded over 8 GPUs')
+            out['c5_shard'] = side_workload(device, dist, 50, 4, 'h36m', 16, 10, 3, 'configs[4]: batch 128 sharded over 8 GPUs')
+            out['boundary'] = boundary_leg(device, dist, spec, params, 256, 10, 2)
     if rank == 0:
         if world == 1 and args.cpu_seconds > 0:
             out['cpu_baseline'] = cpu_baseline(spec, params, args.cpu_seconds, args.cpu_crops)

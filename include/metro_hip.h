@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define METRO_ABI_VERSION 4
+#define METRO_ABI_VERSION 5
 
 typedef enum MetroStatus {
     METRO_OK = 0,
@@ -94,7 +94,9 @@ typedef struct MetroLayerInfo {
     int32_t h_in, w_in, c_in, h_out, w_out, c_out, kh, kw, stride, dilation, pad_top, pad_left;
     int32_t has_prologue, relu, has_residual, res_stride, res_offset;
     int32_t out_dtype;     /* MetroDType of the layer output in the workspace                    */
-    int64_t out_offset;    /* byte offset of the output tensor in the workspace                  */
+    int64_t out_offset;    /* byte offset of the output tensor in the workspace.  The 'logits' layer of an f16 plan
+                            * whose head runs as one launch (head_f16) NEVER writes this slot during metro_forward:
+                            * the logits stay on chip; only metro_forward_upto(last_layer = logits) fills it       */
     int64_t out_bytes_per_image;
     double  flops_per_image; /* 2*MACs (convs only), SURVEY.md section 8d accounting              */
     int64_t out2_offset;   /* fused launches with a second output tensor (shortcut+conv1 pairs,  */
@@ -119,6 +121,18 @@ int  metro_plan_param_info(const MetroPlan* plan, int32_t index, MetroParamInfo*
 int32_t metro_plan_num_layers(const MetroPlan* plan);
 int  metro_plan_layer_info(const MetroPlan* plan, int32_t index, MetroLayerInfo* out);
 double metro_plan_flops_per_image(const MetroPlan* plan);
+/* Which kernel instantiation layer `index` runs on at batch n (1 <= n <= max_batch): the choice depends on the layer's
+ * shape AND on the batch (tile counts against the 256 CUs), so parity established at one batch does not transfer to another
+ * unless the id is the same.  Writes a NUL-terminated id such as "conv3x3_f16_slab<128x256,rows384,bufs2,tps1,kc64,ws3>" or
+ * "conv_igemm_f16_dma<128x128,bk64,s4,pro>+pair" ("a & b" when the layer launches two kernels).  A dry run of the layer's
+ * dispatch code: nothing is launched and no device is needed.  tests/test_kernel_coverage.py requires every id the
+ * BASELINE configurations dispatch at their per-GPU batch to be the id of a single-kernel test that compares with the oracle. */
+int  metro_plan_layer_kernel(const MetroPlan* plan, int32_t index, int32_t n, char* buf, int32_t buf_len);
+/* Test instrumentation for the single-kernel entry points below (thread-local): mode 0 off (default); 1 every launch on this
+ * thread appends its kernel id to the string metro_last_kernel_id() returns; 2 DRY RUN -- entry points record the id and
+ * return METRO_OK without launching.  Setting a mode clears the string. */
+int  metro_kernel_notes(int32_t mode);
+const char* metro_last_kernel_id(void);
 /* Binds the uploaded parameter blob (device pointer, metro_plan_param_bytes() long). */
 int  metro_plan_bind_params(MetroPlan* plan, const void* d_param_blob);
 
@@ -196,16 +210,6 @@ int  metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d
 int  metro_conv_f16_gemm8p(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                            const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
                            int32_t split, void* d_out2, void* stream);
-/* conv2 (3x3, BN + ReLU folded) -> conv3 (1x1, bias) -> + shortcut of one bottleneck unit in ONE launch (reference
- * resnet_v2.py:130-138): d2 = the 3x3 layer's descriptor, d3 = the 1x1 layer's (has_residual), for the 256-wide
- * bottlenecks on 16x16 maps (block3 of the stride-16 / stride-32 nets: c 256 -> 256 -> 1024, rate 1).  d_t2 receives
- * conv2's output (a real tensor, fp16 [n,16,16,256]); four workgroups per image hand their quarters of it to each other
- * inside the launch through d_flags: uint32 [2 n], zero before the first call on it (the launch leaves it zero).
- * The grid is persistent and fully resident; the launch returns METRO_ERR_INVALID_ARG for any other pair of layers.
- * EXPERIMENT: measured slower than the two separate launches (measured dead ends); metro_forward does not use it. */
-int  metro_conv_f16_conv2_conv3(const MetroConvDesc* d2, const void* d_t1, const void* d_w2, const float* d_bias2, void* d_t2,
-                                const MetroConvDesc* d3, const void* d_w3, const float* d_bias3, const void* d_residual,
-                                void* d_out, void* d_flags, void* stream);
 /* Stem 7x7/2 convolution (+bias) and zero-padded 3x3/2 max-pool in one launch (reference resnet_v2.py:219-224,
  * resnet_utils.py:138-185).  d_prepped = metro_prep_input_f16 output [n,side+6,side+8,4] fp16, d_w packed
  * [64][7][8][4] fp16, d_out fp16 [n,side/4,side/4,64].  side % 32 == 0. */
@@ -248,6 +252,17 @@ int  metro_maxpool3x3s2_zeropad(const void* d_in, void* d_out, int32_t n, int32_
 int64_t metro_softargmax_scratch_bytes(int32_t n, int32_t side, int32_t n_joints_head);
 int  metro_softargmax(const void* d_logits, int32_t n, const MetroSpec* spec, int32_t precise,
                       void* d_partials, float* d_poses_out, void* stream);
+
+/* The volumetric head in ONE launch, as metro_forward runs it in f16 mode for heads of <= 160 channels (head_f16.hip):
+ * postnorm BN + ReLU on the raw residual stream (reference resnet_v2.py:229), the 1x1 logits convolution + bias (:233-236,
+ * fp32 accumulators, architectures.py:34), the per-joint softmax statistics of every 64-pixel slab from the on-chip logits
+ * tile (volumetric.py:227-235, tfu.py:466-499), then the slab fold / mm decode / root-relative / gather of metro_softargmax.
+ * d_x fp16 [n, side, side, c_in]; d_w fp16 [depth * J][c_in]; d_bias fp32; d_pro_scale / d_pro_shift fp16 [c_in];
+ * d_partials: metro_head_f16_scratch_bytes(); d_logits_out: optional fp32 NHWC logits dump (NULL in the product path). */
+int64_t metro_head_f16_scratch_bytes(int32_t n, int32_t side, int32_t n_joints_head);
+int  metro_head_f16(const void* d_x, const void* d_w, const float* d_bias, const void* d_pro_scale, const void* d_pro_shift,
+                    int32_t n, int32_t c_in, const MetroSpec* spec, void* d_partials, float* d_logits_out, float* d_poses_out,
+                    void* stream);
 
 /* Evaluation metrics, the step after the path (reference
  * src/main.py:339-359): per (pose, joint) root-relative distance in mm before and after rigid

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('METRO_HIP_LIB') or os.path.join(HERE, 'libmetro_hip.so')   # override: timing experiments
 
 METRO_MAX_JOINTS = 64
-ABI_VERSION = 4          # include/metro_hip.h METRO_ABI_VERSION
+ABI_VERSION = 5          # include/metro_hip.h METRO_ABI_VERSION
 METRO_PREC_F16, METRO_PREC_F32, METRO_PREC_F64 = 0, 1, 2
 METRO_F16, METRO_F32, METRO_F64 = 0, 1, 2
 PARAM_CONV_W, PARAM_BIAS, PARAM_PRO_SCALE, PARAM_PRO_SHIFT = 0, 1, 2, 3
@@ -69,6 +69,9 @@ SIGNATURES = {
     'metro_plan_layer_info': (C.c_int, [_P, C.c_int32, C.POINTER(MetroLayerInfo)]),
     'metro_plan_flops_per_image': (C.c_double, [_P]),
     'metro_plan_bind_params': (C.c_int, [_P, _P]),
+    'metro_plan_layer_kernel': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]),
+    'metro_kernel_notes': (C.c_int, [C.c_int32]),
+    'metro_last_kernel_id': (C.c_char_p, []),
     'metro_plan_set_graph_max_batch': (C.c_int, [_P, C.c_int32]),
     'metro_forward': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
     'metro_forward_upto': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32]),
@@ -77,7 +80,6 @@ SIGNATURES = {
     'metro_conv_f64acc': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f16_pair': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
     'metro_conv_f16_gemm8p': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
-    'metro_conv_f16_conv2_conv3': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P]),
     'metro_conv_f16_next': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     'metro_stem_pool_f16': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     'metro_stem_pool_f32in': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
@@ -93,6 +95,8 @@ SIGNATURES = {
     'metro_backproject_root_depth': (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(MetroSpec), C.c_int32, C.c_int32, _P, _P]),
     'metro_to_orig_cam': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     'metro_heatmap_to_25d': (C.c_int, [_P, C.c_int32, C.POINTER(MetroSpec), _P, _P]),
+    'metro_head_f16_scratch_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'metro_head_f16': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(MetroSpec), _P, _P, _P, _P]),
     'metro_softargmax': (C.c_int, [_P, C.c_int32, C.POINTER(MetroSpec), C.c_int32, _P, _P, _P]),
     'metro_last_error': (C.c_char_p, []),
     'metro_abi_version': (C.c_int32, []),

@@ -184,6 +184,7 @@ bool conv3x3_c64_supported(const MetroConvDesc& d) {
 
 int launch_conv3x3_c64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out, hipStream_t stream) {
     if (!conv3x3_c64_supported(d)) { set_error("conv3x3_c64: unsupported layer"); return METRO_ERR_UNSUPPORTED; }
+    if (note_kernel("conv3x3_c64")) return METRO_OK;
     C64Args a;
     a.in = static_cast<const half_t*>(in); a.w = static_cast<const half_t*>(w); a.bias = bias; a.out = static_cast<half_t*>(out);
     a.m_total = d.n * d.h_out * d.w_out; a.h = d.h_out; a.w_map = d.w_out; a.relu = d.relu;

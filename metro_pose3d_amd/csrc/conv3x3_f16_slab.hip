@@ -104,14 +104,8 @@ __device__ __forceinline__ void slab_static_for(F&& f) {
     }
 }
 
-// 16-byte write-through store (sc1): the payload of an in-launch hand-off to another workgroup (guide, rule R1)
-__device__ __forceinline__ void slab_store16_sc1(void* p, uint4 v) {
-    const metro_u32x4 w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
-}
-
-// One tile: cout [n0, n0 + TM) of pixels [m0, m0 + TN).  SC1: the output is handed to other workgroups of this launch.
-template <class Cfg, bool SC1>
+// One tile: cout [n0, n0 + TM) of pixels [m0, m0 + TN).
+template <class Cfg>
 __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __restrict__ in, const half_t* __restrict__ w,
                                           const float* __restrict__ bias, half_t* __restrict__ out, int halo, int m0, int n0,
                                           char* smem, int tid) {
@@ -365,8 +359,7 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
         if (m >= a.m_total || co >= a.c_out) continue;
         const uint4 v = *reinterpret_cast<const uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16);
         if (co + 8 <= a.c_out) {
-            if constexpr (SC1) slab_store16_sc1(out + (size_t)m * a.c_out + co, v);
-            else store_out16<2>(out + (size_t)m * a.c_out + co, v);
+            store_out16<2>(out + (size_t)m * a.c_out + co, v);
         } else {
             const half8_t x = *reinterpret_cast<const half8_t*>(&v);
 #pragma unroll
@@ -391,226 +384,15 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
     }
     const int tile_n = lid / tiles_m;
     const int tile_m = lid % tiles_m;
-    slab_tile<Cfg, false>(a, in, w, bias, out, halo, tile_n * Cfg::TN, tile_m * Cfg::TM, smem, threadIdx.x);
-}
-
-// =====================================================================================================================
-// conv2 (3x3) + conv3 (1x1) + bias + shortcut add of a 256-wide bottleneck on 16x16 maps (block3 of the stride-16/32 nets;
-// reference resnet_v2.py:130-138) in ONE launch.
-//
-// Why: at batch 64 these are 16 384 pixels per layer; conv2 (19 GFLOP) and conv3 (9 GFLOP) each take ~24 us as their own
-// launches although their arithmetic needs 8 and 4 -- ramp, drain and the T2 round trip.  Fusing them inside a CU needs
-// T1 (conv2's input) or T2 (its output) of the whole image in LDS (128 KiB each) next to the other layer's state, which
-// does not fit; FOUR CUs per image do it:
-//   phase A  block (img, q) computes T2[img][:, 64 q .. 64 q + 63] with the tap-reuse tile above (64 cout x 256 px = one
-//            image) and writes it to HBM with write-through (sc1) stores: T2 stays a real tensor of the plan;
-//   hand-off every wave drains its stores, one lane bumps the image's arrival counter and polls it until the four
-//            quarters are there (guide: "handoff-flag", write-through payload + drained flag, no release fence), then one
-//            `buffer_inv sc1`.  The W3 ring is primed meanwhile.  The four blocks of an image sit on one XCD (a speed
-//            bonus, not a correctness assumption);
-//   phase B  T2[img] (128 KiB) is LDS-DMA'd whole, conv3's cout quarter 256 q .. 256 q + 255 runs as one 256 px x 256 cout
-//            tile (8 waves of 128 cout x 64 px) with W3 streamed through a 2 x 16 KiB ring, + bias + shortcut in fp32, one
-//            fp16 rounding, stores through an LDS tile.
-// The grid is persistent (<= one block per CU, every block resident: the poll cannot wait for an unscheduled block) and
-// walks images img, img + grid/4, ...; the counters are reset by the last of the four blocks to leave.
-struct Conv23Args {
-    ConvArgs a2;                       // the 3x3 layer: 256 -> 256 on 16x16, bias + ReLU
-    const half_t* t1; const half_t* w2; const float* b2; half_t* t2;
-    const half_t* w3; const float* b3; const half_t* res; half_t* out;
-    unsigned* flags;                   // [n][2]: arrivals, departures (zero between launches)
-    int n;
-};
-
-#ifndef METRO_DBG_F23
-#define METRO_DBG_F23 0      // timing experiments only (knock-outs; results invalid)
-#endif
-namespace f23 {
-using Cfg = SlabCfg<1, 8, 2, 1, 320, 2, 3>;           // phase A tile: 64 cout x 256 px, one kernel row per step
-constexpr int PX = 256, CM = 256, CO = 1024, COQ = 256;
-constexpr int T2_ROW = CM * 2;                         // bytes per pixel row of T2 in LDS
-constexpr int T2_BYTES = PX * T2_ROW;                  // 128 KiB
-constexpr int W3_OFF = T2_BYTES;
-constexpr int W3_STAGE = COQ * 64;                     // 256 cout rows x 32 k: 16 KiB
-constexpr int LDS_BYTES = W3_OFF + 2 * W3_STAGE;       // 160 KiB
-constexpr int KST = CM / 32;                           // K stages of conv3
-constexpr int STG_ROW = COQ * 2 + 16;                  // epilogue tile row
-static_assert(LDS_BYTES >= Cfg::LDS_BYTES && PX * STG_ROW <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS");
-}  // namespace f23
-
-__global__ __launch_bounds__(512) void conv3x3_conv1x1_fused_kernel(Conv23Args g) {
-    using namespace f23;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned smem_base = (unsigned)(size_t)(lds_void3_t*)smem;
-    // blocks b, b+8, b+16, b+24 (one XCD) are the four quarters of an image
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int q = idx & 3;
-    const int ngrp = gridDim.x >> 2;
-
-#pragma unroll 1
-    for (int img = (idx >> 2) * 8 + xcd; img < g.n; img += ngrp) {
-        // the lane-derived address tables of the two phases are rebuilt per image and per phase: hoisted out of the loop they
-        // would stay live across the other phase (256 registers: 128 of them accumulators)
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        // ---- phase A: this block's 64 channels of T2[img] --------------------------------------------------------
-        slab_tile<Cfg, true>(g.a2, g.t1, g.w2, g.b2, g.t2, g.a2.dil * g.a2.w_out, img * PX, q * 64, smem, tid);
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 63;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int frag_row = lane & 31, frag_half = lane >> 5;
-        const int wave_m = wave >> 2, wave_n = wave & 3;    // phase B: 128 cout x 64 px per wave
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave: its write-through stores are out
-        __syncthreads();                                        // (and the epilogue tile has been read: LDS is free)
-        // ---- W3 ring primed while the siblings finish ------------------------------------------------------------
-        const half_t* w3q = g.w3 + (size_t)q * COQ * CM;
-        auto issue_w3 = [&](int s, int slot) {                  // stage s = k [32 s, 32 s + 32) of all 256 rows
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int qi = wave * 2 + i;                    // 16 rows x 64 B per instruction
-                const int row = qi * 16 + (lane >> 2), ch = lane & 3;
-                slab_dma16(w3q + (size_t)row * CM + s * 32 + ((ch ^ ((row >> 2) & 3)) * 8),
-                           __builtin_amdgcn_readfirstlane(smem_base + W3_OFF + slot * W3_STAGE + qi * 1024));
-            }
-        };
-        issue_w3(0, 0);
-        issue_w3(1, 1);
-        if (tid == 0) {
-            __hip_atomic_fetch_add(g.flags + 2 * img, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int spins = 0;                                      // bounded: a lost sibling gives wrong numbers, not a hung GPU
-            while (!(METRO_DBG_F23 & 2) && __hip_atomic_load(g.flags + 2 * img, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4u && ++spins < (1 << 22))
-                __builtin_amdgcn_s_sleep(2);
-#if !(METRO_DBG_F23 & 1)
-            asm volatile("buffer_inv sc1" ::: "memory");
-#endif
-        }
-        __syncthreads();
-        // ---- T2[img] -> LDS: [px][256 ch], 16-byte chunk c of pixel p at chunk c ^ (p & 15) ---------------------------
-        const half_t* t2i = g.t2 + (size_t)img * PX * CM;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int t = wave * 16 + i;                        // 2 pixel rows per instruction
-            const int row = 2 * t + (lane >> 5), ch = lane & 31;
-            slab_dma16(t2i + (size_t)row * CM + ((ch ^ (row & 15)) * 8), __builtin_amdgcn_readfirstlane(smem_base + t * 1024));
-        }
-        floatx16 acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        unsigned arow[4], brow[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave_m * 128 + i * 32 + frag_row;
-            arow[i] = W3_OFF + row * 64 + ((frag_half ^ ((row >> 2) & 3)) << 4);
-        }
-        int bsw[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int px = wave_n * 64 + j * 32 + frag_row;
-            brow[j] = px * T2_ROW;
-            bsw[j] = px & 15;
-        }
-        // ---- conv3: 8 K stages; W3(s+1) is issued at the top of stage s into the slot stage s-1 read -----------------
-#pragma unroll
-        for (int s = 0; s < ((METRO_DBG_F23 & 4) ? 1 : KST); ++s) {
-            slab_wait_barrier<0>();                             // W3(s) (s = 0: T2 and W3(1) too) landed everywhere, stage s-1 read
-            if (s >= 1 && s + 1 < KST) issue_w3(s + 1, (s + 1) & 1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                half8_t af[4], bf[2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    af[i] = *reinterpret_cast<const half8_t*>(smem + ((arow[i] + (s & 1) * W3_STAGE) ^ (kk << 5)));
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int chunk = s * 4 + kk * 2 + frag_half;
-                    bf[j] = *reinterpret_cast<const half8_t*>(smem + brow[j] + ((chunk ^ bsw[j]) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
-        }
-        __syncthreads();                                        // T2 / W3 reads done: the epilogue tile overlays them
-        // ---- epilogue: + bias + shortcut (fp32), one rounding, LDS tile [px][256 cout], full-line stores -------------
-        const half_t* resi = g.res + (size_t)img * PX * CO + q * COQ;
-        half_t* outi = g.out + (size_t)img * PX * CO + q * COQ;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int col = wave_m * 128 + i * 32 + 8 * qd + 4 * frag_half;
-                const floatx4 bv = *reinterpret_cast<const floatx4*>(g.b3 + q * COQ + col);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int prow = wave_n * 64 + j * 32 + frag_row;
-                    half4_t rv = {};
-                    if (!(METRO_DBG_F23 & 8)) rv = *reinterpret_cast<const half4_t*>(resi + (size_t)prow * CO + col);
-                    half4_t hv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) hv[e] = (half_t)(acc[i][j][4 * qd + e] + bv[e] + (float)rv[e]);
-                    *reinterpret_cast<half4_t*>(smem + prow * STG_ROW + col * 2) = hv;
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < PX * (COQ / 8) / 512; ++r) {
-            const int item = tid + r * 512;
-            const int prow = item >> 5, ch = item & 31;
-            const uint4 v = *reinterpret_cast<const uint4*>(smem + prow * STG_ROW + ch * 16);
-            store_out16<2>(outi + (size_t)prow * CO + ch * 8, v);
-        }
-        __syncthreads();                                        // the tile has been read before the next image's phase A
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(g.flags + 2 * img + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == 3u) {                                    // all four are past their poll: reset for the next launch
-                __hip_atomic_store(g.flags + 2 * img, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(g.flags + 2 * img + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
-bool conv3x3_conv1x1_fused_supported(const MetroConvDesc& d2, const MetroConvDesc& d3) {
-    static const int enabled = tuning_knob("METRO_CONV23_FUSED", 1);
-    return enabled && conv3x3_slab_supported(d2) && d2.c_in == 256 && d2.c_out == 256 && d2.h_out == 16 && d2.w_out == 16 &&
-           d2.dilation == 1 && d2.relu && d3.kh == 1 && d3.kw == 1 && d3.stride == 1 && d3.c_in == 256 && d3.c_out == 1024 &&
-           d3.n == d2.n && d3.h_in == 16 && d3.w_in == 16 && d3.h_out == 16 && d3.w_out == 16 && d3.in_pix_stride == 256 &&
-           !d3.has_prologue && !d3.relu && d3.has_residual && d3.res_stride == 1 && d3.res_offset == 0 && d3.res_h == 16 &&
-           d3.res_w == 16 && d3.in_dtype == METRO_F16 && d3.out_dtype == METRO_F16;
-}
-
-int launch_conv3x3_conv1x1_fused(const MetroConvDesc& d2, const void* t1, const void* w2, const float* b2, void* t2,
-                                 const MetroConvDesc& d3, const void* w3, const float* b3, const void* res, void* out,
-                                 unsigned* flags, hipStream_t stream) {
-    if (!conv3x3_conv1x1_fused_supported(d2, d3)) {
-        set_error("conv2+conv3 fused launch: unsupported pair of layers");
-        return METRO_ERR_INVALID_ARG;
-    }
-    Conv23Args g;
-    g.a2 = make_conv_args(d2);
-    g.t1 = static_cast<const half_t*>(t1); g.w2 = static_cast<const half_t*>(w2); g.b2 = b2; g.t2 = static_cast<half_t*>(t2);
-    g.w3 = static_cast<const half_t*>(w3); g.b3 = b3; g.res = static_cast<const half_t*>(res); g.out = static_cast<half_t*>(out);
-    g.flags = flags; g.n = d2.n;
-    auto kern = conv3x3_conv1x1_fused_kernel;
-    static PerDeviceInt grid_cap;
-    int cap = 0;
-    if (const int st = ensure_dyn_lds_and_grid_cap(reinterpret_cast<const void*>(kern), 512, f23::LDS_BYTES, grid_cap, "conv3x3_conv1x1_fused", 1, &cap)) return st;
-    int grid = (cap / 32) * 32;                                 // every block resident; four quarters x eight XCDs
-    if (grid > 4 * ((d2.n + 7) / 8) * 8) grid = 4 * ((d2.n + 7) / 8) * 8;
-    if (grid < 32) { set_error("conv2+conv3 fused launch needs 32 resident blocks, the device offers %d", cap); return METRO_ERR_INVALID_ARG; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), f23::LDS_BYTES, stream, g);
-    return launch_status("conv3x3_conv1x1_fused");
+    slab_tile<Cfg>(a, in, w, bias, out, halo, tile_n * Cfg::TN, tile_m * Cfg::TM, smem, threadIdx.x);
 }
 
 template <class Cfg>
 static int launch_slab_cfg(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias,
                            half_t* out, int halo, hipStream_t stream) {
+    if (note_kernel("conv3x3_f16_slab<%dx%d,rows%d,bufs%d,tps%d,kc%d,ws%d>", Cfg::TM, Cfg::TN, Cfg::SLAB_ROWS, Cfg::SLAB_BUFS, Cfg::TPS,
+                    Cfg::KC, Cfg::W_STAGES))
+        return METRO_OK;
     auto kern = conv3x3_f16_slab_kernel<Cfg>;
     static PerDeviceInt attr_done;
     if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), Cfg::LDS_BYTES, attr_done, "conv3x3_f16_slab")) return st;

@@ -256,8 +256,11 @@ __global__ __launch_bounds__(g8::NT) void conv_gemm8p_kernel(
         ktile(std::integral_constant<int, 0>{}, t);
         ktile(std::integral_constant<int, 1>{}, t + 1);
     }
-    g8_wait_vm<0>();                      // the re-staged last tile must have landed before the ring is overwritten
-    if (wr == 0) g8_barrier();                   // re-align the two groups: every wave is done reading the ring
+    g8_wait_vm<0>();                      // this wave's re-staged last tile has landed ...
+    if (wr == 0) g8_barrier();            // re-align the two groups: every wave is done reading the ring
+    g8_barrier();                         // ... and so has EVERY wave's (group 1 leaves its last loop barrier with up to six
+                                          // LDS-DMAs in flight; vmcnt orders only a wave's own): nobody writes the epilogue
+                                          // tile over the ring before all of them drained
 
     // ---- epilogue: accumulators (+bias, ReLU) -> LDS [pixel][cout] fp16 -> full-line stores (+ shortcut) ----
     const bool second = a.split > 0 && n0 >= a.split;     // fused pair: this cout tile belongs to one of the two outputs
@@ -359,6 +362,8 @@ int launch_conv_gemm8p(const MetroConvDesc& d, const void* in, const void* w, co
         a.split = split->split; a.c_out2 = split->c_out2; a.relu2 = split->relu2;
         out2 = split->out2;
     }
+    if (note_kernel("conv_gemm8p<256x256%s>%s%s", d.has_prologue ? ",pro" : "", d.has_residual ? "+res" : "", a.split > 0 ? "+pair" : ""))
+        return METRO_OK;
     const int tiles_m = (d.c_out + g8::TM - 1) / g8::TM;
     const int tiles_n = (a.m_total + g8::TN - 1) / g8::TN;
     const half_t* r = d.has_residual ? static_cast<const half_t*>(res) : nullptr;

@@ -615,6 +615,9 @@ static int launch_dma_cfg2(const ConvArgs& a, const half_t* in, const half_t* w,
         set_error("conv_igemm_f16_dma: split %d is not a multiple of the %d-wide cout tile", a.split, Cfg::TM);
         return METRO_ERR_INVALID_ARG;
     }
+    if (note_kernel("conv_igemm_f16_dma<%dx%d,bk%d,s%d%s%s>%s%s%s", Cfg::TM, Cfg::TN, Cfg::BK, Cfg::STAGES, PROLOGUE ? ",pro" : "",
+                    FASTK ? "" : ",ktail", res ? "+res" : "", a.split > 0 ? "+pair" : "", out_f32 ? "+f32out" : ""))
+        return METRO_OK;
     auto kern = conv_igemm_f16_dma_kernel<Cfg, PROLOGUE, FASTK>;
     constexpr int lds = Cfg::MAIN_BYTES + (PROLOGUE ? Cfg::PRO_BYTES : 0);
     static PerDeviceInt attr_done;
@@ -659,6 +662,7 @@ bool conv_f16_fuse2_supported(const MetroConvDesc& d, int c2) {
 static int launch_fuse2(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias, const half_t* res,
                         void* out, const ConvFuse2& f, hipStream_t stream) {
     using Cfg = DmaFuse256x64;
+    if (note_kernel("conv_igemm_f16_fuse2<256x64>%s", res ? "+res" : "")) return METRO_OK;
     auto kern = conv_igemm_f16_fuse2_kernel<Cfg>;
     constexpr int lds = Cfg::MAIN_BYTES + 64 * Cfg::TM * 2 + 2 * Cfg::TM * 2;
     static PerDeviceInt attr_done;

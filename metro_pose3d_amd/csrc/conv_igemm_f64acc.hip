@@ -154,6 +154,8 @@ __global__ __launch_bounds__(P_NT) void conv_igemm_f64acc_kernel(
 template <typename TIn, typename TAct>
 static int launch_t(const ConvArgs& a, bool pro, const void* in, const double* w, const double* bias,
                     const double* ps, const double* pb, const void* res, void* out, hipStream_t stream) {
+    if (note_kernel("conv_igemm_f64acc<in%d,act%d%s>%s", (int)sizeof(TIn) * 8, (int)sizeof(TAct) * 8, pro ? ",pro" : "", res ? "+res" : ""))
+        return METRO_OK;
     const int tiles_c = (a.c_out + P_TN - 1) / P_TN;
     const int tiles_p = (a.m_total + P_TM - 1) / P_TM;
     if (pro)

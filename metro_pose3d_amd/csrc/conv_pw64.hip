@@ -375,6 +375,9 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
 
 template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false>
 static int launch_pw(Pw64Args a, hipStream_t stream) {
+    if (note_kernel("conv_pw64<k%d,wm%d%s%s%s%s>", K, WM, PRO ? ",pro" : "", RES ? ",res" : "",
+                    MODE2 == 1 ? ",pair" : MODE2 == 2 ? ",next" : "", RSUB ? ",ressub" : ""))
+        return METRO_OK;
     auto kern = conv_pw64_kernel<K, WM, PRO, RES, MODE2, RSUB>;
     constexpr int lds = pw::lds_bytes<K, WM, RES, MODE2>();
     a.n_tiles = (a.m_total + pw::Lay<K, WM>::TN - 1) / pw::Lay<K, WM>::TN;

@@ -44,6 +44,16 @@ inline int tuning_knob(const char* name, int dflt) {
 #endif
 }
 
+// ---- dispatch notes ----------------------------------------------------------------------------------------
+// Which kernel INSTANTIATION a layer runs on depends on its shape and on the batch (tile counts vs 256 CUs).  Every
+// leaf launcher calls note_kernel() FIRST -- before any HIP call -- with the id of the instantiation it is about to
+// launch.  Off (the default) it is one thread-local load; mode 1 appends the id to a thread-local string
+// (metro_last_kernel_id); mode 2 is a DRY RUN: the id is recorded and the launcher returns METRO_OK without touching
+// the device (metro_plan_layer_kernel, and the coverage test in tests/test_kernel_coverage.py, work without a GPU).
+struct KernelNotes { int mode; char ids[256]; };
+KernelNotes& kernel_notes();
+bool note_kernel(const char* fmt, ...) __attribute__((format(printf, 1, 2)));   // true = dry run: skip the launch
+
 // 16-byte activation store of an epilogue.  METRO_NT_STORES (A/B builds only) marks them non-temporal:
 //   1 = the streaming kernels whose outputs exceed the L2 (stem, conv_pw64, conv3x3_c64), 2 = every conv kernel.
 typedef unsigned int metro_u32x4 __attribute__((ext_vector_type(4)));
@@ -209,11 +219,6 @@ bool conv3x3_c64_supported(const MetroConvDesc& d);
 int launch_conv3x3_c64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out, hipStream_t stream);
 // 3x3 stride-1 convs with tap reuse from an LDS-resident activation slab
 bool conv3x3_slab_supported(const MetroConvDesc& d);
-// conv2 + conv3 + shortcut of a 256-wide bottleneck on 16x16 maps in one launch (conv3x3_f16_slab.hip)
-bool conv3x3_conv1x1_fused_supported(const MetroConvDesc& d2, const MetroConvDesc& d3);
-int launch_conv3x3_conv1x1_fused(const MetroConvDesc& d2, const void* t1, const void* w2, const float* b2, void* t2,
-                                 const MetroConvDesc& d3, const void* w3, const float* b3, const void* res, void* out,
-                                 unsigned* flags, hipStream_t stream);
 int launch_conv3x3_slab(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out,
                         hipStream_t stream);
 int launch_conv_f64acc(const MetroConvDesc& d, const void* in, const double* w, const double* bias,

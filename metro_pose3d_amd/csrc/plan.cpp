@@ -26,6 +26,22 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
+static thread_local KernelNotes g_notes = {0, ""};
+KernelNotes& kernel_notes() { return g_notes; }
+bool note_kernel(const char* fmt, ...) {
+    if (g_notes.mode == 0) return false;
+    const size_t used = strlen(g_notes.ids);
+    if (used + 2 < sizeof(g_notes.ids)) {
+        size_t at = used;
+        if (used && used + 4 < sizeof(g_notes.ids)) { memcpy(g_notes.ids + at, " & ", 3); at += 3; }   // several kernels: a & b
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(g_notes.ids + at, sizeof(g_notes.ids) - at, fmt, ap);
+        va_end(ap);
+    }
+    return g_notes.mode == 2;
+}
+
 int validate_conv_desc(const MetroConvDesc* d) {
     METRO_CHECK_ARG(d != nullptr, "conv desc is NULL");
     METRO_CHECK_ARG(d->n > 0 && d->h_in > 0 && d->w_in > 0 && d->c_in > 0 && d->h_out > 0 &&
@@ -479,7 +495,14 @@ int build_plan(MetroPlan* p) {
     for (int s = 0; s < S_COUNT; ++s) {
         p->slot_offset[s] = off;
         int64_t bytes = p->slot_bytes_per_image[s] * p->max_batch;
-        if (s == S_PART) bytes = softargmax_scratch_bytes(p->max_batch, sp.proc_side / sp.stride, sp.n_joints_head);
+        if (s == S_PART) {
+            const int hs = sp.proc_side / sp.stride;
+            bytes = softargmax_scratch_bytes(p->max_batch, hs, sp.n_joints_head);
+            // the one-launch head writes one (m, S, Sx, Sy, Sz) fp32 record per (image, 64-pixel slab, joint): more slabs
+            // than the two-launch path's <= 64 once the heat map has > 4096 pixels (side >= 96, e.g. proc_side 384 at stride 4)
+            if (head_fused)
+                bytes = std::max(bytes, (int64_t)p->max_batch * head_f16_slabs(hs) * sp.n_joints_head * 5 * 4);
+        }
         off = align_up(off + bytes, 256);
     }
     p->workspace_bytes = off;
@@ -516,6 +539,68 @@ int build_plan(MetroPlan* p) {
     return METRO_OK;
 }
 
+// One layer of the plan at batch n.  `dump_logits`: the one-launch head also writes the fp32 logits tensor (layer dumps).
+int launch_layer(MetroPlan* p, int li, const float* images, int n, float* poses, char* ws, hipStream_t stream, bool dump_logits) {
+    Layer& L = p->layers[li];
+    auto slot_ptr = [&](int slot) -> void* {
+        if (slot == S_IMAGES) return const_cast<float*>(images);
+        if (slot < 0) return nullptr;
+        return ws + p->slot_offset[slot];
+    };
+    auto prm = [&](int idx) -> const void* { return idx < 0 ? nullptr : p->d_params + p->params[idx].offset; };
+    switch (L.kind) {
+        case LK_PREP:
+            return launch_prep_input_f16(images, n, p->spec.proc_side, slot_ptr(L.out_slot), stream);
+        case LK_POOL:
+            return launch_maxpool(slot_ptr(L.in_slot), slot_ptr(L.out_slot), n, L.cd.h_in, L.cd.w_in, L.cd.c_in, p->act_dtype, stream);
+        case LK_CONV: {
+            MetroConvDesc cd = L.cd;
+            cd.n = n;
+            if (p->fast && L.head_fused) {
+                float* dump = dump_logits ? static_cast<float*>(slot_ptr(L.out_slot)) : nullptr;
+                return launch_head_f16(slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)), prm(L.p_scale),
+                                       prm(L.p_shift), n, L.cd.c_in, L.cd.c_out, p->spec.n_joints_head, p->spec.depth, L.cd.h_in,
+                                       static_cast<float*>(slot_ptr(S_PART)), dump, stream);
+            }
+            if (p->fast && L.stem_pool == 2)
+                return launch_stem_pool_f32in(images, prm(L.p_w), static_cast<const float*>(prm(L.p_bias)), slot_ptr(L.out_slot), n,
+                                              p->spec.proc_side, stream);
+            if (p->fast && L.stem_pool)
+                return launch_stem_pool_f16(slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
+                                            slot_ptr(L.out_slot), n, p->spec.proc_side, stream);
+            if (p->fast && L.split > 0) {
+                ConvSplit sp;
+                sp.split = L.split; sp.c_out2 = L.c_out2; sp.relu2 = L.relu2; sp.out2 = slot_ptr(L.out2_slot);
+                return launch_conv_f16_dma(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
+                                           prm(L.p_scale), prm(L.p_shift), nullptr, slot_ptr(L.out_slot), stream, &sp);
+            }
+            if (p->fast && L.f2_w >= 0) {
+                ConvFuse2 f2;
+                f2.w2 = prm(L.f2_w); f2.bias2 = static_cast<const float*>(prm(L.f2_bias));
+                f2.scale2 = prm(L.f2_scale); f2.shift2 = prm(L.f2_shift);
+                f2.out2 = slot_ptr(L.out2_slot); f2.c2 = L.f2_c2;
+                return launch_conv_f16_dma(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
+                                           nullptr, nullptr, slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream, nullptr, &f2);
+            }
+            if (p->fast)
+                return launch_conv_f16(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
+                                       prm(L.p_scale), prm(L.p_shift), slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream);
+            return launch_conv_f64acc(cd, slot_ptr(L.in_slot), static_cast<const double*>(prm(L.p_w)),
+                                      static_cast<const double*>(prm(L.p_bias)), static_cast<const double*>(prm(L.p_scale)),
+                                      static_cast<const double*>(prm(L.p_shift)), slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream);
+        }
+        case LK_SOFTARGMAX: {
+            if (poses == nullptr) { set_error("metro_forward: poses_out is NULL"); return METRO_ERR_INVALID_ARG; }
+            const SoftArgmaxArgs a = make_softargmax_args(p->spec, n);
+            if (L.head_fused)
+                return launch_softargmax_finalize(static_cast<const float*>(slot_ptr(S_PART)), a, head_f16_slabs(a.side), poses, stream);
+            return launch_softargmax(slot_ptr(L.in_slot), a, p->spec.precision, slot_ptr(S_PART), poses, stream);
+        }
+    }
+    set_error("internal: layer %d has unknown kind %d", li, L.kind);
+    return METRO_ERR_STATE;
+}
+
 int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_, hipStream_t stream,
                int last_layer, float* ms_out) {
     METRO_CHECK_ARG(p != nullptr, "plan is NULL");
@@ -531,76 +616,11 @@ int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_
         ev.resize(2 * (last_layer + 1));
         for (auto& e : ev) METRO_HIP_CHECK(hipEventCreate(&e));
     }
-    auto slot_ptr = [&](int slot) -> void* {
-        if (slot == S_IMAGES) return const_cast<float*>(images);
-        if (slot < 0) return nullptr;
-        return ws + p->slot_offset[slot];
-    };
-    auto prm = [&](int idx) -> const void* { return idx < 0 ? nullptr : p->d_params + p->params[idx].offset; };
-
     int st = METRO_OK;
     for (int li = 0; li <= last_layer && st == METRO_OK; ++li) {
-        Layer& L = p->layers[li];
         if (ms_out) METRO_HIP_CHECK(hipEventRecord(ev[2 * li], stream));
-        switch (L.kind) {
-            case LK_PREP:
-                st = launch_prep_input_f16(images, n, p->spec.proc_side, slot_ptr(L.out_slot), stream);
-                break;
-            case LK_POOL:
-                st = launch_maxpool(slot_ptr(L.in_slot), slot_ptr(L.out_slot), n, L.cd.h_in, L.cd.w_in,
-                                    L.cd.c_in, p->act_dtype, stream);
-                break;
-            case LK_CONV: {
-                MetroConvDesc cd = L.cd;
-                cd.n = n;
-                if (p->fast && L.head_fused) {
-                    // layer dumps (metro_forward_upto stopping here) also get the fp32 logits tensor
-                    float* dump = li == last_layer && li + 1 < nl ? static_cast<float*>(slot_ptr(L.out_slot)) : nullptr;
-                    st = launch_head_f16(slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)), prm(L.p_scale),
-                                         prm(L.p_shift), n, L.cd.c_in, L.cd.c_out, p->spec.n_joints_head, p->spec.depth, L.cd.h_in,
-                                         static_cast<float*>(slot_ptr(S_PART)), dump, stream);
-                } else if (p->fast && L.stem_pool == 2) {
-                    st = launch_stem_pool_f32in(images, prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
-                                                slot_ptr(L.out_slot), n, p->spec.proc_side, stream);
-                } else if (p->fast && L.stem_pool) {
-                    st = launch_stem_pool_f16(slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
-                                              slot_ptr(L.out_slot), n, p->spec.proc_side, stream);
-                } else if (p->fast && L.split > 0) {
-                    ConvSplit sp;
-                    sp.split = L.split; sp.c_out2 = L.c_out2; sp.relu2 = L.relu2; sp.out2 = slot_ptr(L.out2_slot);
-                    st = launch_conv_f16_dma(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
-                                             prm(L.p_scale), prm(L.p_shift), nullptr, slot_ptr(L.out_slot), stream, &sp);
-                } else if (p->fast && L.f2_w >= 0) {
-                    ConvFuse2 f2;
-                    f2.w2 = prm(L.f2_w); f2.bias2 = static_cast<const float*>(prm(L.f2_bias));
-                    f2.scale2 = prm(L.f2_scale); f2.shift2 = prm(L.f2_shift);
-                    f2.out2 = slot_ptr(L.out2_slot); f2.c2 = L.f2_c2;
-                    st = launch_conv_f16_dma(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
-                                             nullptr, nullptr, slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream,
-                                             nullptr, &f2);
-                } else if (p->fast)
-                    st = launch_conv_f16(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
-                                         prm(L.p_scale), prm(L.p_shift), slot_ptr(L.res_slot),
-                                         slot_ptr(L.out_slot), stream);
-                else
-                    st = launch_conv_f64acc(cd, slot_ptr(L.in_slot),
-                                            static_cast<const double*>(prm(L.p_w)),
-                                            static_cast<const double*>(prm(L.p_bias)),
-                                            static_cast<const double*>(prm(L.p_scale)),
-                                            static_cast<const double*>(prm(L.p_shift)),
-                                            slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream);
-                break;
-            }
-            case LK_SOFTARGMAX: {
-                if (poses == nullptr) { set_error("metro_forward: poses_out is NULL"); st = METRO_ERR_INVALID_ARG; break; }
-                const SoftArgmaxArgs a = make_softargmax_args(p->spec, n);
-                if (L.head_fused)
-                    st = launch_softargmax_finalize(static_cast<const float*>(slot_ptr(S_PART)), a, head_f16_slabs(a.side), poses, stream);
-                else
-                    st = launch_softargmax(slot_ptr(L.in_slot), a, p->spec.precision, slot_ptr(S_PART), poses, stream);
-                break;
-            }
-        }
+        // layer dumps (metro_forward_upto stopping at the one-launch head) also get the fp32 logits tensor
+        st = launch_layer(p, li, images, n, poses, ws, stream, li == last_layer && li + 1 < nl);
         if (ms_out) METRO_HIP_CHECK(hipEventRecord(ev[2 * li + 1], stream));
     }
     if (ms_out) {
@@ -680,6 +700,34 @@ int metro_plan_layer_info(const MetroPlan* plan, int32_t index, MetroLayerInfo* 
     *out = plan->layers[index].info;
     return METRO_OK;
 }
+
+int metro_plan_layer_kernel(const MetroPlan* plan, int32_t index, int32_t n, char* buf, int32_t buf_len) {
+    METRO_CHECK_ARG(plan && buf && buf_len > 1 && index >= 0 && index < (int)plan->layers.size(), "metro_plan_layer_kernel: bad argument");
+    METRO_CHECK_ARG(n > 0 && n <= plan->max_batch, "metro_plan_layer_kernel: batch %d outside [1, %d]", n, plan->max_batch);
+    // dry run of the layer's dispatch: the leaf launcher records the instantiation it would launch and returns
+    KernelNotes& kn = kernel_notes();
+    const KernelNotes saved = kn;
+    kn.mode = 2; kn.ids[0] = 0;
+    MetroPlan* p = const_cast<MetroPlan*>(plan);
+    const char* saved_params = p->d_params;
+    static const char fake = 0;                       // pointers are never dereferenced in a dry run
+    if (p->d_params == nullptr) p->d_params = &fake;
+    float dummy_poses = 0.f;
+    const int st = launch_layer(p, index, reinterpret_cast<const float*>(&fake), n, &dummy_poses,
+                                const_cast<char*>(&fake), nullptr, false);
+    p->d_params = saved_params;
+    snprintf(buf, (size_t)buf_len, "%s", kn.ids);
+    kn = saved;
+    return st;
+}
+
+int metro_kernel_notes(int32_t mode) {
+    METRO_CHECK_ARG(mode >= 0 && mode <= 2, "metro_kernel_notes: mode must be 0 (off), 1 (record) or 2 (dry run)");
+    KernelNotes& kn = kernel_notes();
+    kn.mode = mode; kn.ids[0] = 0;
+    return METRO_OK;
+}
+const char* metro_last_kernel_id(void) { return kernel_notes().ids; }
 
 int metro_plan_bind_params(MetroPlan* plan, const void* d_param_blob) {
     METRO_CHECK_ARG(plan && d_param_blob, "metro_plan_bind_params: NULL argument");
@@ -796,20 +844,6 @@ int metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d_
                                static_cast<hipStream_t>(stream), nullptr, &f2);
 }
 
-int metro_conv_f16_conv2_conv3(const MetroConvDesc* d2, const void* d_t1, const void* d_w2, const float* d_bias2, void* d_t2,
-                               const MetroConvDesc* d3, const void* d_w3, const float* d_bias3, const void* d_residual,
-                               void* d_out, void* d_flags, void* stream) {
-    METRO_CHECK_ARG(d2 && d3, "conv_f16_conv2_conv3: NULL descriptor");
-    int st = validate_conv_desc(d2);
-    if (st) return st;
-    st = validate_conv_desc(d3);
-    if (st) return st;
-    METRO_CHECK_ARG(d_t1 && d_w2 && d_bias2 && d_t2 && d_w3 && d_bias3 && d_residual && d_out && d_flags,
-                    "conv_f16_conv2_conv3: NULL tensor pointer");
-    return launch_conv3x3_conv1x1_fused(*d2, d_t1, d_w2, d_bias2, d_t2, *d3, d_w3, d_bias3, d_residual, d_out,
-                                        static_cast<unsigned*>(d_flags), static_cast<hipStream_t>(stream));
-}
-
 int metro_conv_f16_gemm8p(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                           const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
                           int32_t split, void* d_out2, void* stream) {
@@ -896,6 +930,28 @@ int metro_softargmax(const void* d_logits, int32_t n, const MetroSpec* spec, int
     METRO_CHECK_ARG(spec->proc_side / spec->stride >= 2, "softargmax: heat-map side must be >= 2");
     const SoftArgmaxArgs a = make_softargmax_args(*spec, n);
     return launch_softargmax(d_logits, a, precise, d_partials, d_poses_out, static_cast<hipStream_t>(stream));
+}
+
+int64_t metro_head_f16_scratch_bytes(int32_t n, int32_t side, int32_t n_joints_head) {
+    if (n <= 0 || side <= 1 || n_joints_head <= 0) return -1;
+    return (int64_t)n * head_f16_slabs(side) * n_joints_head * 5 * (int64_t)sizeof(float);
+}
+
+int metro_head_f16(const void* d_x, const void* d_w, const float* d_bias, const void* d_pro_scale, const void* d_pro_shift,
+                   int32_t n, int32_t c_in, const MetroSpec* spec, void* d_partials, float* d_logits_out, float* d_poses_out,
+                   void* stream) {
+    METRO_CHECK_ARG(d_x && d_w && d_bias && d_pro_scale && d_pro_shift && spec && d_partials && d_poses_out && n > 0,
+                    "head_f16: bad argument");
+    METRO_CHECK_ARG(spec->n_joints_head >= 1 && spec->n_joints_head <= METRO_MAX_JOINTS && spec->n_joints_out >= 1 &&
+                        spec->n_joints_out <= METRO_MAX_JOINTS, "head_f16: joint counts out of range");
+    const int side = spec->proc_side / spec->stride;
+    const SoftArgmaxArgs a = make_softargmax_args(*spec, n);
+    int st = launch_head_f16(d_x, d_w, d_bias, d_pro_scale, d_pro_shift, n, c_in, spec->depth * spec->n_joints_head,
+                             spec->n_joints_head, spec->depth, side, static_cast<float*>(d_partials), d_logits_out,
+                             static_cast<hipStream_t>(stream));
+    if (st) return st;
+    return launch_softargmax_finalize(static_cast<const float*>(d_partials), a, head_f16_slabs(side), d_poses_out,
+                                      static_cast<hipStream_t>(stream));
 }
 
 int metro_softargmax01(const void* d_logits, int32_t n, const MetroSpec* spec, int32_t precise, void* d_partials,

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void prep_input_f16_kernel(const float* __rest
 }
 
 int launch_prep_input_f16(const float* images, int n, int side, void* out, hipStream_t stream) {
+    if (note_kernel("prep_input_f16")) return METRO_OK;
     const long total = (long)n * (side + 6) * (side + 8);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(prep_input_f16_kernel, dim3(blocks), dim3(256), 0, stream, images,
@@ -155,6 +156,8 @@ typedef double doublex2 __attribute__((ext_vector_type(2)));
 int launch_maxpool(const void* in, void* out, int n, int h_in, int w_in, int c, int dtype,
                    hipStream_t stream) {
     const int h_out = (h_in + 2 - 3) / 2 + 1, w_out = (w_in + 2 - 3) / 2 + 1;
+    if (dtype != METRO_F16 && dtype != METRO_F32 && dtype != METRO_F64) { set_error("maxpool: unsupported dtype %d", dtype); return METRO_ERR_INVALID_ARG; }
+    if (note_kernel("maxpool3x3s2_zeropad<%s>", dtype == METRO_F16 ? "f16" : dtype == METRO_F32 ? "f32" : "f64")) return METRO_OK;
     if (dtype == METRO_F16) {
         if (c % 8) { set_error("maxpool f16: channels %d not a multiple of 8", c); return METRO_ERR_INVALID_ARG; }
         const long total = (long)n * h_out * w_out * (c / 8);
@@ -364,6 +367,9 @@ static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void
     const int ppb = SA_NT / quads;
     const int slabs = softargmax_slabs(a.n, a.side);
     const size_t lds = (size_t)ppb * C * 4 * sizeof(AccT);
+    if (note_kernel("softargmax_partial<acc%d,logits%d> & softargmax_finalize<acc%d>", (int)sizeof(AccT) * 8, (int)sizeof(LogitT) * 8,
+                    (int)sizeof(AccT) * 8))
+        return METRO_OK;
     auto kern = softargmax_partial_kernel<AccT, LogitT>;
     if (lds > 64 * 1024) {
         static PerDeviceInt attr_done;
@@ -380,6 +386,7 @@ static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void
 
 int launch_softargmax_finalize(const float* partials, const SoftArgmaxArgs& a, int slabs, float* poses_out,
                                hipStream_t stream, float* coords01_out) {
+    if (note_kernel("softargmax_finalize<acc32>")) return METRO_OK;
     hipLaunchKernelGGL(softargmax_finalize_kernel<float>, dim3(a.n), dim3(64), 0, stream, partials, poses_out, a, slabs, coords01_out);
     return launch_status("softargmax_finalize");
 }

@@ -377,6 +377,7 @@ int launch_stem_pool_f32in(const float* images, const void* w, const float* bias
 
 template <int NSPLIT, bool RAW>
 static int launch_sp(const StemPoolArgs& a, hipStream_t stream) {
+    if (note_kernel("stem_pool_f16<split%d%s>", NSPLIT, RAW ? ",f32in" : "")) return METRO_OK;
     auto kern = stem_pool_f16_kernel<NSPLIT, RAW>;
     constexpr int NT = 64 * sp::MG * NSPLIT;
     static PerDeviceInt cap;

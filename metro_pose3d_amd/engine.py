@@ -110,6 +110,16 @@ class Engine:
             out.append(li)
         return out
 
+    def layer_kernels(self, n: int) -> List[str]:
+        """The kernel instantiation every layer runs on at batch n (metro_plan_layer_kernel: a dry run of the dispatch,
+        no device needed).  The choice depends on the batch; tests/test_kernel_coverage.py holds every id to a test."""
+        out = []
+        buf = C.create_string_buffer(256)
+        for i in range(self.lib.metro_plan_num_layers(self._plan)):
+            check(self.lib.metro_plan_layer_kernel(self._plan, i, int(n), buf, len(buf)), 'metro_plan_layer_kernel')
+            out.append(buf.value.decode())
+        return out
+
     @property
     def flops_per_image(self) -> float:
         return float(self.lib.metro_plan_flops_per_image(self._plan))

@@ -6,7 +6,11 @@ same CLI flag `--model-path`.  Differences that follow from not being TensorFlow
     computed (the reference returns graph tensors to `sess.run` later, inference.py:25-27);
   * `joint_edges` is an int64 ndarray [E, 2] and `joint_names` an object ndarray of `bytes`,
     which is what `sess.run` yields for those constants (main.py:140-141);
-  * `model_path` is the container of modelfile.py (the `.pb` importer is SURVEY row f1).
+  * `model_path` is a frozen `.pb` GraphDef like the reference's (read without TensorFlow, tfgraph.py) or the
+    `.npz` container of modelfile.py;
+  * N is free, as with the reference's `[None, 256, 256, 3]` placeholder (main.py:109-111): the call plans for the
+    batch it is given -- one `metro_forward` for up to 256 crops (kernel dispatch depends on the batch: from 128 crops
+    on the 3x3 layers take 512-pixel tiles and more layers run on the 256 x 256 GEMM kernel), 256-crop chunks beyond.
 Input contract (inference.py:17-18, main.py:109-110): float32 NHWC [N,256,256,3], RGB in [0,1].
 The arithmetic mode defaults to fp16, the reference's default compute dtype (options.py:73);
 pass precision='f64' (or METRO_PRECISION=f64) for the parity mode (fp64 arithmetic inside).
@@ -15,7 +19,8 @@ from __future__ import annotations
 
 import argparse
 import os
-from typing import Dict, Optional, Tuple
+from collections import OrderedDict
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
@@ -24,18 +29,34 @@ from metro_pose3d_amd import _lib
 from metro_pose3d_amd.engine import Engine
 from metro_pose3d_amd.modelfile import load_model
 
-_ENGINES: Dict[Tuple[str, float, str, int], Engine] = {}
-DEFAULT_MAX_BATCH = 64
+# One plan (workspace sized for its max_batch) per (model file, precision, device, batch bucket), least recently used first.
+# Workspace at RN50-s16: 10 MB per crop (2.6 GB at 256 of the 288 GB); the parameter blob (48 MB) is per engine.
+BATCH_BUCKETS = (8, 64, 256)
+MAX_CACHED_ENGINES = 6
+_ENGINES: 'OrderedDict[Tuple[str, float, str, int, int], Engine]' = OrderedDict()
 
 
-def _engine_for(model_path: str, precision: str, device: torch.device) -> Engine:
+def batch_bucket(n: int) -> int:
+    """max_batch of the engine a call with n crops runs on (calls with more than 256 crops are chunked by 256)."""
+    for b in BATCH_BUCKETS:
+        if n <= b:
+            return b
+    return BATCH_BUCKETS[-1]
+
+
+def _engine_for(model_path: str, precision: str, device: torch.device, n: int = 64) -> Engine:
     path = os.path.abspath(model_path)
-    key = (path, os.path.getmtime(path), precision, device.index or 0)
+    key = (path, os.path.getmtime(path), precision, device.index or 0, batch_bucket(n))
     eng = _ENGINES.get(key)
     if eng is None:
         spec, params = load_model(path)
-        eng = Engine(spec, params, precision=precision, max_batch=DEFAULT_MAX_BATCH, device=device)
+        eng = Engine(spec, params, precision=precision, max_batch=key[-1], device=device)
         _ENGINES[key] = eng
+        while len(_ENGINES) > MAX_CACHED_ENGINES:
+            _, old = _ENGINES.popitem(last=False)
+            old.close()
+    else:
+        _ENGINES.move_to_end(key)
     return eng
 
 
@@ -52,13 +73,13 @@ def estimate_pose(images_tensor, model_path, precision: Optional[str] = None):
     if images_tensor.dtype != torch.float32:
         raise ValueError(f'images must be float32 in [0,1] (reference inference.py:18), got {images_tensor.dtype}')
     device = images_tensor.device if images_tensor.is_cuda else torch.device('cuda', torch.cuda.current_device())
-    eng = _engine_for(model_path, precision, device)
+    n = int(images_tensor.shape[0]) if images_tensor.dim() == 4 else 0
+    eng = _engine_for(model_path, precision, device, max(n, 1))
     s = eng.spec.proc_side
     if images_tensor.dim() != 4 or tuple(images_tensor.shape[1:]) != (s, s, 3):
         raise ValueError(f'images must be NHWC [N,{s},{s},3] (reference main.py:109-110), got '
                          f'{tuple(images_tensor.shape)}')
     images = images_tensor.to(device, non_blocking=True).contiguous()
-    n = images.shape[0]
     sk = eng.spec.skeleton
     poses = torch.empty((n, sk.n_out, 3), dtype=torch.float32, device=device)
     with torch.cuda.device(device):

@@ -282,16 +282,25 @@ def structural_params(nodes: Dict[str, 'Node']) -> Dict[str, np.ndarray]:
 
 
 def infer_centered_stride(nodes: Dict[str, 'Node'], params: Dict[str, np.ndarray]) -> Optional[bool]:
-    """True / False from the padding mode of a strided 3x3 bottleneck conv2, None when the graph has none."""
+    """centered_stride of the export, read off the padding modes of the STRIDED 3x3 bottleneck conv2 nodes.
+
+    With centered_stride=True the reference centres exactly ONE block, c[i_last] (resnet_v2.py:278-286,301-309): its
+    strided conv2 is a plain SAME convolution, every other strided conv2 stays explicit Pad + VALID
+    (resnet_utils.py:120-135).  A default stride-16 export therefore has block1/unit_3 VALID and block2/unit_4 SAME.
+    True if ANY strided conv2 is SAME, False if all of them are VALID, None when the graph has no strided unit
+    (stride 4: every block runs atrous; the caller then takes the reference default, options.py:118)."""
+    seen = False
     for n in nodes.values():
         if n.op != 'Conv2D' or '/bottleneck_v2/conv2' not in n.name:
             continue
         strides = _attr_ints(n.attrs.get('strides'))
         if len(strides) == 4 and max(strides) == 2:
             pad = _attr_string(n.attrs.get('padding'))
-            if pad in ('SAME', 'VALID'):
-                return pad == 'SAME'
-    return None
+            if pad == 'SAME':
+                return True
+            if pad == 'VALID':
+                seen = True
+    return False if seen else None
 
 
 def extract_model(nodes: Dict[str, Node], stride: Optional[int] = None, centered_stride: Optional[bool] = None):

@@ -2,7 +2,7 @@
 """Joins rocprofv3 --pmc counter_collection CSVs (one dir per pass) into a per-dispatch table for
 one forward pass and labels the dispatches with the plan's layer names.
 
-    python profiles/pmc_table.py gpurun_out/pmc1 [forward_index]
+    python profiles/pmc_table.py gpurun_out/pmc1 [forward_index] [arch stride dataset batch]
 """
 import csv
 import glob
@@ -31,7 +31,8 @@ def main():
     fwd = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     from metro_pose3d_amd import ModelSpec
     from metro_pose3d_amd.engine import Engine
-    infos = Engine(ModelSpec(50, 16, 'h36m'), None, 'f16', 64).layer_infos()
+    arch, stride, dataset, batch = (int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6])) if len(sys.argv) > 6 else (50, 16, 'h36m', 64)
+    infos = Engine(ModelSpec(arch, stride, dataset), None, 'f16', batch).layer_infos()
     names = []
     for li in infos:
         names.append(li.name.decode())

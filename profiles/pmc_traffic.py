@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(tsv, tag, batch=64):
-    from bench import kernels_sha16
+def main(tsv, tag, batch=64, arch=50, stride=16, dataset='h36m'):
+    from bench import kernels_sha16, workload_key
     from metro_pose3d_amd import ModelSpec, _lib
     from metro_pose3d_amd.engine import Engine
-    infos = Engine(ModelSpec(50, 16, 'h36m'), None, 'f16', batch).layer_infos()
+    infos = Engine(ModelSpec(arch, stride, dataset), None, 'f16', batch).layer_infos()
     algo = sum(li.algo_act_bytes_per_image * batch + li.algo_param_bytes for li in infos if li.kind == _lib.LAYER_CONV)
     rows = list(csv.DictReader(open(tsv), delimiter='\t'))
     conv = [r for r in rows if r['layer'].startswith(('conv1', 'block', 'logits'))]
@@ -27,10 +27,12 @@ def main(tsv, tag, batch=64):
     fa = sum(float(r['FETCH_SIZE']) for r in rows)
     wa = sum(float(r['WRITE_SIZE']) for r in rows)
     print(json.dumps({
-        'source': f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --batch {batch} --steps 2 '
-                  f'--warmup 1 --cpu-seconds 0 --no-extras`, second forward pass; see profiles/{tag}_pmc_layers.tsv',
+        'source': f'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --arch {arch} --stride {stride} '
+                  f'--dataset {dataset} --batch {batch} --steps 2 --warmup 1 --cpu-seconds 0 --no-extras`, second forward pass; '
+                  f'see profiles/{tag}_pmc_layers.tsv',
         'correction': 'FETCH_SIZE counts 64 B per 128 B request for wide coalesced reads on gfx950 (MI355X_MICROARCH.md, '
                       'HBM section): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024',
+        'workload': workload_key(arch, stride, dataset, batch),
         'batch': batch,
         'kernels_sha16': kernels_sha16(),
         'conv_launches': len(conv),
@@ -45,4 +47,5 @@ def main(tsv, tag, batch=64):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 64)
+    a = sys.argv
+    main(a[1], a[2], int(a[3]) if len(a) > 3 else 64, *((int(a[4]), int(a[5]), a[6]) if len(a) > 6 else ()))

@@ -31,3 +31,23 @@ def test_stale_traffic_is_refused(tmp_path, monkeypatch):
     r = {}
     bench.attach_traffic(r, 64)
     assert 'traffic' not in r and 'stale' in r['traffic_note']
+
+
+def test_matching_hash_wins_whatever_the_file_times(tmp_path, monkeypatch):
+    """After a checkout file times are arbitrary: with several committed profiles of one workload the one collected for the
+    current kernel sources is attached, also when a stale one is newer; other workloads are keyed by name."""
+    import time
+    sha = bench.kernels_sha16()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    monkeypatch.setattr(bench, 'kernels_sha16', lambda: sha)
+    _write(str(tmp_path), 'r03a_pmc_traffic.json', 64, sha, 4.0e9)
+    time.sleep(0.02)
+    _write(str(tmp_path), 'r02z_pmc_traffic.json', 64, 'deadbeefdeadbeef', 5.0e9)      # newer AND stale
+    with open(tmp_path / 'profiles' / 'r03a_c4_pmc_traffic.json', 'w') as f:
+        json.dump({'workload': bench.workload_key(101, 8, 'many19', 32), 'batch': 32, 'kernels_sha16': sha, 'conv_launches': 101,
+                   'conv_hbm_bytes_per_forward': 9.0e9, 'conv_hbm_bytes_per_launch_avg': 9.0e9 / 101}, f)
+    r, r4 = {}, {}
+    bench.attach_traffic(r, 64)
+    bench.attach_traffic(r4, bench.workload_key(101, 8, 'many19', 32))
+    assert r['traffic'] == 4.0e9 and 'r03a_pmc_traffic.json' in r['traffic_note']
+    assert r4['traffic'] == 9.0e9

@@ -310,3 +310,113 @@ def test_hipgraph_replay_is_bit_identical(cuda, monkeypatch):
         out.zero_()
         eng.forward(x, out=out)
         assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('arch,stride,dataset,n', [(101, 8, 'many19', 32), (50, 4, 'h36m', 16), (50, 16, 'many19', 64)],
+                         ids=['C4-rn101-s8-J19-b32', 'C5-rn50-s4-J17-b16', 'C3-rn50-s16-J19-b64'])
+def test_batch_independence_of_the_other_baseline_configs(cuda, arch, stride, dataset, n):
+    """tests/test_f16_layerwise.py holds every launch of these configurations to the fp16 oracle at n = 1; at their
+    per-GPU batch (BASELINE.json configs[2..4] sharded 8 ways) other kernel instantiations run (tests/test_kernel_coverage.py
+    checks each of them on its own).  This transfers the n = 1 parity to the real batch END TO END: below 128 crops every
+    tile shape accumulates in the same order, so the batch and its split 1 + (n - 1) must give the same BITS, layer
+    outputs included."""
+    spec = ModelSpec(arch, stride, dataset)
+    params, images = _setup(spec, n, gain=synth.logit_gain_for(arch, stride))
+    x = torch.from_numpy(images).to(cuda)
+    eng = Engine(spec, params, 'f16', max_batch=n, device=cuda)
+    kern_n, kern_1 = eng.layer_kernels(n), eng.layer_kernels(1)
+    assert kern_n != kern_1, 'the dispatch at the real batch is expected to differ from the dispatch at n = 1'
+    whole = eng.forward(x).clone()
+    assert torch.isfinite(whole).all()
+    parts = torch.cat([eng.forward(x[:1]).clone(), eng.forward(x[1:]).clone()])
+    if not torch.equal(whole, parts):            # name the first layer whose bits depend on the batch
+        for i, li in enumerate(eng.layer_infos()):
+            if li.kind == _lib.LAYER_SOFTARGMAX:
+                continue
+            a = eng.forward_upto(x, i)
+            b = torch.cat([eng.forward_upto(x[:1], i), eng.forward_upto(x[1:], i)])
+            assert torch.equal(a, b), f'{li.name.decode()}: {kern_n[i]} (n = {n}) vs {kern_1[i]} / {eng.layer_kernels(n - 1)[i]}'
+    assert torch.equal(whole, parts)
+
+
+def test_estimate_pose_plans_for_the_batch_it_is_given(cuda, tmp_path, monkeypatch):
+    """The reference's placeholder is [None, 256, 256, 3] (main.py:109-111): a caller may pass any N.  256 crops go through ONE
+    metro_forward(n = 256) -- the dispatch the north star's batch-256 figure is measured on (512-pixel 3x3 tiles, more
+    layers on the 256 x 256 GEMM) -- not through four calls of 64; the result agrees with the chunked one to within the
+    distance of two fp16 summation orders (test_large_batch_tile_shapes_agree_with_small_batches), and 300 crops are
+    chunked 256 + 44."""
+    from metro_pose3d_amd import inference as INF, save_model
+    spec = ModelSpec(50, 16, 'h36m')
+    params, images = _setup(spec, 300, gain=synth.logit_gain_for(50, 16))
+    path = str(tmp_path / 'rn50s16.npz')
+    save_model(path, spec, params)
+    calls = []
+    real = Engine.forward
+
+    def counting(self, imgs, out=None):
+        calls.append((self.max_batch, int(imgs.shape[0])))
+        return real(self, imgs, out=out)
+
+    monkeypatch.setattr(Engine, 'forward', counting)
+    x = torch.from_numpy(images).to(cuda)
+    p256, _, _ = INF.estimate_pose(x[:256], path)
+    assert calls == [(256, 256)], calls
+    calls.clear()
+    p64 = torch.cat([INF.estimate_pose(x[i:i + 64], path)[0] for i in range(0, 256, 64)])
+    assert calls == [(64, 64)] * 4, calls
+    a, b = p256.cpu().numpy(), p64.cpu().numpy()
+    assert np.isfinite(a).all() and np.abs(a - b).max() < 6.0 and np.abs(a - b).mean() < 0.6, (np.abs(a - b).max(), np.abs(a - b).mean())
+    calls.clear()
+    p300, _, _ = INF.estimate_pose(x, path)
+    assert calls == [(256, 256), (256, 44)], calls
+    assert torch.equal(p300[:256], p256)
+    calls.clear()
+    INF.estimate_pose(x[:3], path)
+    assert calls == [(8, 3)], calls
+    assert len(INF._ENGINES) <= INF.MAX_CACHED_ENGINES
+
+
+def _two_rank_worker(rank, world, port, spec_json, n, q):
+    import os
+    import torch.distributed as dist
+    from metro_pose3d_amd.dist import shard_range, sharded_forward
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        spec = ModelSpec.from_json(spec_json)
+        params, images = _setup(spec, n, gain=synth.logit_gain_for(spec.arch, spec.stride))
+        dev = torch.device('cuda', 0)                      # BOTH ranks on the one GPU of the box
+        b, e = shard_range(n, rank, world)
+        eng = Engine(spec, params, 'f16', max_batch=max(e - b, 1), device=dev)
+        # the real engine on this rank's shard; the pose all-gather runs on gloo (host tensors): RCCL needs one GPU per rank
+        got = sharded_forward(lambda t: eng.forward(t.to(dev)).cpu(), torch.from_numpy(images))
+        q.put((rank, got.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n', [16, 7], ids=['even', 'ragged'])
+def test_two_ranks_real_engine_gather_equals_single_process(cuda, n):
+    """Row (e) with the REAL engine: two processes (world 2), each running metro_forward on its contiguous shard of the batch,
+    one all-gather of the poses -- bit-identical to the single-process run of the whole batch.  Both ranks share cuda:0 and
+    the gather goes over gloo, which is what a 1-GPU box can show; the RCCL path is bench.py --gpus N."""
+    import socket
+    import torch.multiprocessing as mp
+    spec = ModelSpec(50, 16, 'many19')
+    params, images = _setup(spec, n, gain=synth.logit_gain_for(50, 16))
+    want = Engine(spec, params, 'f16', max_batch=n, device=cuda).forward(torch.from_numpy(images).to(cuda)).cpu().numpy()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, spec.to_json(), n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert res[r].shape == want.shape and np.array_equal(res[r], want), f'rank {r}: gathered poses differ from the single-process run'

@@ -163,7 +163,7 @@ def test_reader_against_official_protobuf_encoder(tmp_path):
 
 
 # ---- graphs shaped like a TF 1.13 export of this model (reference main.py:143-161) -------------------------------------
-def _tf_like_graph(spec, params, fp16_folded, centered, drop_names=False):
+def _tf_like_graph(spec, params, fp16_folded, drop_names=False):
     """variable Const -> Identity '<var>/read' -> Cast -> Conv2D / BiasAdd, BN parameters -> FusedBatchNorm, encoded with
     the official protobuf runtime.  fp16_folded: what `fold_constants` + `strip_unused_nodes` leave of the default fp16
     export -- Cast(read(variable)) of every TRAINABLE variable cast at use (tfu.py:426-440: conv kernels and biases;
@@ -224,7 +224,9 @@ def _tf_like_graph(spec, params, fp16_folded, centered, drop_names=False):
         pre = bn(sc + '/preact', x)
         short = conv(sc + '/shortcut', pre, u.stride, 'SAME', bias=True) if u.c_in != u.c_out else x
         r = bn(sc + '/conv1/BatchNorm', conv(sc + '/conv1', pre))
-        if u.stride == 2 and not centered:       # conv2d_same: explicit Pad + VALID (resnet_utils.py:125-135)
+        # conv2d_same: explicit Pad + VALID (resnet_utils.py:125-135) unless THIS unit is the centred one: only the last
+        # unit of block c[i_last] is (resnet_v2.py:278-286), e.g. block2 of a stride-16 net -- block1 stays Pad + VALID
+        if u.stride == 2 and not u.centered:
             g.node.add(name=sc + '/Pad', op='Pad', input=[r])
             r = conv(sc + '/conv2', sc + '/Pad', 2, 'VALID')
         else:
@@ -263,14 +265,16 @@ def _expected_params(params, fp16_folded):
 @pytest.mark.parametrize('fp16_folded,drop_names', [(False, False), (True, False), (True, True)],
                          ids=['fp32-unfolded', 'fp16-folded-cast-names', 'fp16-folded-anonymous'])
 @pytest.mark.parametrize('centered', [True, False], ids=['centered', 'not-centered'])
-def test_tf_export_shaped_graph_is_read_by_structure(tmp_path, fp16_folded, drop_names, centered):
+@pytest.mark.parametrize('stride', [16, 32], ids=['s16', 's32'])
+def test_tf_export_shaped_graph_is_read_by_structure(tmp_path, fp16_folded, drop_names, centered, stride):
     """The default export is fp16: after fold_constants the kernel of a conv is a Const named after the CAST node
     ('.../conv1/Cast/_7__cf__7'), or not after the layer at all -- the reader finds it through the Conv2D that consumes
-    it, and reads centered_stride off the strided conv2's padding mode."""
-    spec = ModelSpec(50, 16, 'h36m', base_width=8, centered_stride=centered)
+    it, and reads centered_stride off the strided conv2 nodes' padding modes: a centred export has ONE SAME-padded strided
+    conv2 (block2 at stride 16, block3 at stride 32) behind Pad + VALID ones (block1; blocks 1-2)."""
+    spec = ModelSpec(50, stride, 'h36m', base_width=8, centered_stride=centered)
     params = synth.make_params(50, spec.n_head_channels, 8, seed=11)
     path = tmp_path / 'export.pb'
-    path.write_bytes(_tf_like_graph(spec, params, fp16_folded, centered, drop_names))
+    path.write_bytes(_tf_like_graph(spec, params, fp16_folded, drop_names))
     spec2, params2 = load_model(str(path))
     assert spec2 == spec and spec2.centered_stride == centered
     exp = _expected_params(params, fp16_folded)
@@ -290,7 +294,7 @@ def test_hip_path_from_tf_export_shaped_graph_matches_oracle(cuda, tmp_path, fp1
     spec = ModelSpec(50, 16, 'h36m', base_width=16, centered_stride=False)
     params = synth.make_params(50, spec.n_head_channels, 16, seed=4, logit_gain=0.8)
     path = tmp_path / 'export.pb'
-    path.write_bytes(_tf_like_graph(spec, params, fp16_folded, centered=False))
+    path.write_bytes(_tf_like_graph(spec, params, fp16_folded))
     images = synth.make_images(2)
     poses, _, names = estimate_pose(images, str(path), precision='f64')
     ref = OF.forward(H.oracle_spec(spec), _expected_params(params, fp16_folded), images, torch.float64).numpy()
