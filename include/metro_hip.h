@@ -88,6 +88,12 @@ typedef struct MetroParamInfo {
     int64_t bytes;
 } MetroParamInfo;
 
+#define METRO_FUSED_CONV1_IN_FRONT 1      /* '<unit>/conv1+conv2': conv1 (1x1 on the pre-activated unit input, folded BN + ReLU,
+                                           * reference resnet_v2.py:119,127-128) runs on the 3x3 layer's LDS-resident input slab;
+                                           * the layer's input tensor is the unit's RAW input (c_in = its channels)          */
+#define METRO_FUSED_PROJECTION_SHORTCUT 2 /* conv3 launch that computes the unit's projection shortcut (resnet_v2.py:122-125)
+                                           * from the unit's raw input instead of reading a shortcut tensor: has_residual = 0 */
+
 typedef struct MetroLayerInfo {
     char    name[96];
     int32_t kind;          /* 0 input-prep, 1 conv, 2 max-pool, 3 soft-argmax partial, 4 finalize */
@@ -100,8 +106,10 @@ typedef struct MetroLayerInfo {
     int64_t out_bytes_per_image;
     double  flops_per_image; /* 2*MACs (convs only), SURVEY.md section 8d accounting              */
     int64_t out2_offset;   /* fused launches with a second output tensor (shortcut+conv1 pairs,  */
-    int32_t out2_channels; /*   conv3+next conv1): its workspace offset / channels; -1 / 0 = none */
-    int32_t reserved;
+    int32_t out2_channels; /*   conv3+next conv1): its workspace offset / channels; -1 / 0 = none.
+                            * METRO_FUSED_CONV1_IN_FRONT layers: conv1's output, which lives in LDS during
+                            * metro_forward and is written here ONLY by metro_forward_upto(last_layer = this layer) */
+    int32_t fused_flags;   /* METRO_FUSED_*: other layers of the unit computed inside this launch        */
     /* algorithmic HBM bytes of this launch, every tensor it touches counted once (bench.py: the minimum the measured
      * rocprofv3 FETCH_SIZE/WRITE_SIZE traffic is compared with): activations read + written per image (input, outputs,
      * shortcut), and the parameter tensors it reads (once per launch, batch independent). */
@@ -202,6 +210,20 @@ int  metro_conv_f16_pair(const MetroConvDesc* d, const void* d_in, const void* d
 int  metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                          const void* d_residual, void* d_out, const void* d_w2, const float* d_bias2,
                          const void* d_scale2, const void* d_shift2, void* d_out2, int32_t c2, void* stream);
+/* block1/unit_1 in two launches (the unit's input has only 64 channels, so recomputing beats storing):
+ * metro_conv_f16_conv1_conv2 -- conv1 (1x1, 64 -> 64, folded BN + ReLU) on relu(x * pro_scale + pro_shift), then conv2 (3x3, SAME,
+ *   folded BN + ReLU; d = ITS descriptor, relu = 1) in one launch; conv1's output lives in LDS only (reference
+ *   resnet_v2.py:119,127-132).  d_x fp16 [n,h,w,64], d_w1 fp16 [64][64], d_w2 fp16 [64][3][3][64], d_out fp16 [n,h,w,64].
+ * metro_conv_f16_next_proj -- metro_conv_f16_next with the unit's PROJECTION shortcut computed in the launch:
+ *   d_out = fp16(conv3(d_in) + bias) + fp16(Wsc * relu(d_x * pro_scale + pro_shift) + bias_sc)   (resnet_v2.py:119,122-125,134-138)
+ *   d_out2 = relu(W2 * relu(d_out * scale2 + shift2) + bias2)                                    (unit u+1, :119,127-128)
+ *   d->has_residual = 0; d_x fp16 [.., 64] the unit's raw input, d_w_sc fp16 [256][64], d_bias_sc fp32 [256]. */
+int  metro_conv_f16_conv1_conv2(const MetroConvDesc* d, const void* d_x, const void* d_w1, const float* d_bias1, const void* d_pro_scale,
+                                const void* d_pro_shift, const void* d_w2, const float* d_bias2, void* d_out, void* stream);
+int  metro_conv_f16_next_proj(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias, const void* d_x,
+                              const void* d_w_sc, const float* d_bias_sc, const void* d_pro_scale, const void* d_pro_shift, void* d_out,
+                              const void* d_w2, const float* d_bias2, const void* d_scale2, const void* d_shift2, void* d_out2,
+                              int32_t c2, void* stream);
 /* The same contract as metro_conv_f16 / metro_conv_f16_pair on the 256 x 256 x 64 GEMM kernel with the 8-phase
  * two-wave-group schedule (conv_gemm8p.hip), which metro_forward picks for the deep-K 1x1 layers with at least one
  * tile per CU (conv1, projection shortcut, shortcut+conv1 pair of blocks 3-4: reference resnet_v2.py:122-128).

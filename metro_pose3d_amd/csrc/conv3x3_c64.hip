@@ -14,6 +14,15 @@
 //   * ordering: one counted s_waitcnt vmcnt(2) per tile (the only VMEM operations younger than the next slab's DMA
 //     are this wave's 2 row stores) + two raw s_barrier.
 // Arithmetic = the tap-reuse kernel's: fp16 operands, fp32 accumulate over (tap, channel), fp16(relu(acc + bias)).
+//
+// PRE1 (round 3): conv1 of the SAME unit in front of it, for block1/unit_1 whose input has only 64 channels (the pooled
+// stem output): the slab that is DMA'd is the raw unit input x, and every wave turns its 32 slab rows into
+// t1 = fp16(relu(W1 . fp16(relu(x * scale + shift)) + b1)) IN PLACE (pre-activation BN + ReLU, conv1 with its folded BN + ReLU:
+// reference resnet_v2.py:119,127-128) -- 8 more MFMAs per wave and tile, W1 in registers as A fragments; the halo rows
+// are recomputed by both tiles that share them.  The 3x3 then runs on t1 exactly as before (taps outside the image still
+// read the zero area: conv2d_same pads t1, not x).  t1 never exists in HBM: the unit loses a launch (projection
+// shortcut + conv1 pair -> nothing; the shortcut moves into the conv3 launch, conv_pw64.hip PSC) and 1152 of its 2304
+// bytes per pixel.  Same arithmetic as the separate launches: one fp16 rounding per tensor (oracle/f16emu.py unit_conv1).
 #include "metro_common.h"
 
 namespace metro {
@@ -60,8 +69,15 @@ struct C64Args {
     const float* bias;     // [64]
     half_t* out;           // [m_total][64]
     int m_total, h, w_map, relu, n_tiles, tiles_per_block;
+    // PRE1: conv1 (1x1, 64 -> 64, folded BN + ReLU) on the pre-activated slab in front of the 3x3
+    const half_t* w1;      // [64][64]
+    const float* bias1;    // [64]
+    const half_t* pro_scale;   // [64] pre-activation BN of the unit
+    const half_t* pro_shift;
+    half_t* t1_dump;       // layer dumps / tests only (NULL in the product path): conv1's output [m_total][64] as the 3x3 reads it
 };
 
+template <bool PRE1>
 __global__ __launch_bounds__(c64::NT) void conv3x3_c64_kernel(C64Args a) {
     using namespace c64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,6 +130,28 @@ __global__ __launch_bounds__(c64::NT) void conv3x3_c64_kernel(C64Args a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) bias_v[q][e] = bv[e];
     }
+    // PRE1: W1 as A fragments (both 32-cout tiles x 4 k steps), its bias in the accumulator layout, the pre-activation per k step
+    half8_t w1f[2][4], ps1[4], pb1[4];
+    float bias1_v[2][4][4];
+    if constexpr (PRE1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                w1f[i][kk] = *reinterpret_cast<const half8_t*>(a.w1 + (size_t)(i * 32 + frag_row) * C + kk * 16 + frag_half * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const floatx4 bv = *reinterpret_cast<const floatx4*>(a.bias1 + i * 32 + 8 * q + 4 * frag_half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bias1_v[i][q][e] = bv[e];
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            ps1[kk] = *reinterpret_cast<const half8_t*>(a.pro_scale + kk * 16 + frag_half * 8);
+            pb1[kk] = *reinterpret_cast<const half8_t*>(a.pro_shift + kk * 16 + frag_half * 8);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // weights + first slab + zero area
 
     for (int t = t_begin; t < t_end; ++t) {
@@ -124,6 +162,37 @@ __global__ __launch_bounds__(c64::NT) void conv3x3_c64_kernel(C64Args a) {
         }
         if (t + 1 < t_end) issue_slab(t + 1, buf ^ 1);     // other buffer: last read before the barrier above
 
+        if constexpr (PRE1) {
+            // ---- conv1 in place: wave w owns slab rows [32 w, 32 w + 32): all 64 input channels of a row are read before
+            //      its 64 output channels are written, nobody else touches these rows before the barrier below ----
+            char* sp = smem + SLAB_OFF + buf * SLAB_BYTES;
+            const int srow = wave * 32 + frag_row;
+            const int r_base = srow * 128 + ((frag_half ^ ((srow >> 1) & 7)) << 4);
+            floatx16 a1[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { a1[0][e] = 0.f; a1[1][e] = 0.f; }
+            const half8_t z = {};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                half8_t bf = *reinterpret_cast<const half8_t*>(sp + (r_base ^ (kk << 5)));
+                bf = __builtin_elementwise_max(bf * ps1[kk] + pb1[kk], z);            // fp16 FMA + ReLU, one rounding
+                a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f[0][kk], bf, a1[0], 0, 0, 0);
+                a1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f[1][kk], bf, a1[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    half4_t hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[e] = (half_t)fmaxf(a1[i][4 * q + e] + bias1_v[i][q][e], 0.f);
+                    // channels i*32 + 8q + 4 half ..+3 = 16-byte chunk (4i + q), byte 8 * half inside it
+                    *reinterpret_cast<half4_t*>(sp + srow * 128 + ((((4 * i + q) ^ ((srow >> 1) & 7)) << 4) | (frag_half << 3))) = hv;
+                    if (a.t1_dump != nullptr && srow >= halo && srow < halo + TN)      // the tile's own rows, once
+                        *reinterpret_cast<half4_t*>(a.t1_dump + (size_t)(t * TN + srow - halo) * C + i * 32 + 8 * q + 4 * frag_half) = hv;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         // ---- per-lane tap rows of this tile (slab row, or the zero area for taps outside the image) ----
         const int m0 = t * TN;
         const int tl = wn * 32 + frag_row;                 // tile-local pixel
@@ -182,22 +251,29 @@ bool conv3x3_c64_supported(const MetroConvDesc& d) {
     return d.w_out <= 64 && c64::TN % d.w_out == 0 && (d.h_out * d.w_out) % c64::TN == 0 && m >= 4 * c64::TN;
 }
 
-int launch_conv3x3_c64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out, hipStream_t stream) {
+int launch_conv3x3_c64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out, hipStream_t stream,
+                       const ConvPre1* pre1) {
     if (!conv3x3_c64_supported(d)) { set_error("conv3x3_c64: unsupported layer"); return METRO_ERR_UNSUPPORTED; }
-    if (note_kernel("conv3x3_c64")) return METRO_OK;
+    const bool p1 = pre1 != nullptr && pre1->w1 != nullptr;
+    if (note_kernel(p1 ? "conv3x3_c64<pre1>" : "conv3x3_c64")) return METRO_OK;
     C64Args a;
     a.in = static_cast<const half_t*>(in); a.w = static_cast<const half_t*>(w); a.bias = bias; a.out = static_cast<half_t*>(out);
     a.m_total = d.n * d.h_out * d.w_out; a.h = d.h_out; a.w_map = d.w_out; a.relu = d.relu;
     a.n_tiles = a.m_total / c64::TN;
-    static PerDeviceInt cap;
+    a.w1 = p1 ? static_cast<const half_t*>(pre1->w1) : nullptr; a.bias1 = p1 ? pre1->bias1 : nullptr;
+    a.pro_scale = p1 ? static_cast<const half_t*>(pre1->pro_scale) : nullptr;
+    a.pro_shift = p1 ? static_cast<const half_t*>(pre1->pro_shift) : nullptr;
+    a.t1_dump = p1 ? static_cast<half_t*>(pre1->t1_dump) : nullptr;
+    auto kern = p1 ? conv3x3_c64_kernel<true> : conv3x3_c64_kernel<false>;
+    static PerDeviceInt cap[2];
     int grid_cap = 0;
-    if (const int st = ensure_dyn_lds_and_grid_cap(reinterpret_cast<const void*>(conv3x3_c64_kernel), c64::NT, c64::LDS_BYTES, cap,
+    if (const int st = ensure_dyn_lds_and_grid_cap(reinterpret_cast<const void*>(kern), c64::NT, c64::LDS_BYTES, cap[p1 ? 1 : 0],
                                                    "conv3x3_c64", 1, &grid_cap))
         return st;
     // contiguous tile ranges per block: consecutive tiles share their halo rows through the L2 of one XCD
     a.tiles_per_block = (a.n_tiles + grid_cap - 1) / grid_cap;
     const int grid = (a.n_tiles + a.tiles_per_block - 1) / a.tiles_per_block;
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(c64::NT), c64::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(c64::NT), c64::LDS_BYTES, stream, a);
     return launch_status("conv3x3_c64");
 }
 

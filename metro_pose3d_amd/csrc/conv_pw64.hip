@@ -17,6 +17,11 @@
 //                  reference resnet_v2.py:122-128): 4 more MFMAs on the B fragments already in registers;
 //       MODE2 = 2  conv1 of the NEXT unit on this launch's output (after the shortcut add), pre-activation
 //                  applied in the row-wise pass, second GEMM from the LDS-resident tile (resnet_v2.py:119,127).
+//       PSC        (with MODE2 = 2, block1/unit_1) the unit's PROJECTION shortcut is computed here instead of being
+//                  read: a second 8 KB input tile (the unit's raw 64-channel input), Wsc in registers next to W3,
+//                  sc = fp16(Wsc . fp16(relu(x * scale + shift)) + bias_sc) (resnet_v2.py:119,122-125) added to
+//                  fp16(conv3 + bias) in registers -- 128 instead of 512 shortcut bytes per pixel, and the launch that
+//                  wrote the shortcut tensor (512 more) is gone.
 // Arithmetic is that of the tiled kernel: fp32 accumulate, fp16(conv + bias), then the fp16 shortcut add.
 #include <cstdlib>
 
@@ -46,6 +51,9 @@ struct Pw64Args {
     const half_t* scale2;      // [256]  (MODE2 = 2)
     const half_t* shift2;
     half_t* out2;              // [m_total][64]
+    const half_t* x_sc;        // PSC: [m_total][64] raw unit input; pro_scale / pro_shift are ITS pre-activation
+    const half_t* w_sc;        // PSC: [256][64]
+    const float* bias_sc;      // PSC: [256]
     int m_total, n_tiles;
     int c_out;                 // 256 * (number of 256-channel halves); block b serves half b % halves
     // sub-sampled shortcut (units with stride 2, reference resnet_v2.py:113-118: max_pool2d 1x1 stride 2 of the
@@ -70,16 +78,16 @@ struct Lay {
     static constexpr int RI = TN / 16;              // row-wise iterations = shortcut DMA instructions = stores per wave
     static constexpr int OUT_BYTES = TN * OUT_ROW;
     static constexpr int RES_BYTES = TN * 512;
-    static constexpr int PAR_BYTES = 1024 + 256 + 4 * K;   // bias[256] f32 | bias2[64] f32 | pro scale[K] | pro shift[K] fp16
+    static constexpr int PAR_BYTES = 1024 + 256 + 4 * K + 1024;   // bias[256] f32 | bias2[64] f32 | pro scale[K] | pro shift[K] fp16 | bias_sc[256] f32 (PSC)
     static constexpr int X_OFF = 0;                 // 2 buffers
     static constexpr int OUT_OFF = X_OFF + 2 * X_BYTES;
     static constexpr int PAR_OFF = OUT_OFF + OUT_BYTES;
     static constexpr int RES_OFF = PAR_OFF + PAR_BYTES;   // 2 buffers (RES)
     static_assert(X_BYTES % (1024 * NW) == 0, "input tile must split evenly over the waves");
 };
-template <int K, int WM, bool RES, int MODE2>
+template <int K, int WM, bool RES, int MODE2, bool PSC = false>
 constexpr int lds_bytes() {
-    return Lay<K, WM>::RES_OFF + (RES ? 2 * Lay<K, WM>::RES_BYTES : 0) + (MODE2 == 2 ? 64 * 256 * 2 : 0);
+    return Lay<K, WM>::RES_OFF + (RES ? 2 * Lay<K, WM>::RES_BYTES : PSC ? 2 * Lay<K, WM>::X_BYTES : 0) + (MODE2 == 2 ? 64 * 256 * 2 : 0);
 }
 }  // namespace pw
 
@@ -101,19 +109,21 @@ __device__ __forceinline__ void pw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false>
+template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false, bool PSC = false>
 __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     using namespace pw;
     using L = Lay<K, WM>;
     static_assert((WM == 4 && K <= 128) || (WM == 8 && K <= 512), "weights must fit the register file as MFMA fragments");
     static_assert(MODE2 == 0 || (K == 64 && WM == 4), "second outputs are block1 shapes");
+    static_assert(!PSC || (MODE2 == 2 && !PRO && !RES), "in-launch projection shortcut: conv3 + next conv1 of block1/unit_1");
     constexpr int KK = K / 16, WN = L::WN, NI = L::NI, TN = L::TN, XI = L::XI, RI = L::RI;
     constexpr int X_BYTES = L::X_BYTES, X_OFF = L::X_OFF, OUT_OFF = L::OUT_OFF, PAR_OFF = L::PAR_OFF, RES_OFF = L::RES_OFF,
                   RES_BYTES = L::RES_BYTES, SL_BYTES = L::SL_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void_t;
     const unsigned smem_base = (unsigned)(size_t)(lds_void_t*)smem;
-    constexpr int W2_OFF = RES_OFF + (RES ? 2 * RES_BYTES : 0);
+    constexpr int XS_OFF = RES_OFF;                          // PSC: two buffers of the unit-input tile where the shortcut rows would be
+    constexpr int W2_OFF = RES_OFF + (RES ? 2 * RES_BYTES : PSC ? 2 * X_BYTES : 0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -149,6 +159,14 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
             wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)((wm * NI + i) * 32 + frag_row) * K + kk * 16 + frag_half * 8);
+    half8_t wsf[NI][KK];                                     // PSC: the projection shortcut's weights, same fragment layout
+    if constexpr (PSC) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+                wsf[i][kk] = *reinterpret_cast<const half8_t*>(a.w_sc + (size_t)((wm * NI + i) * 32 + frag_row) * K + kk * 16 + frag_half * 8);
+    }
     half8_t w2f[4];
     if constexpr (MODE2 == 1) {
         if (wave < 4) {
@@ -162,7 +180,9 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     half_t* pro_l = reinterpret_cast<half_t*>(smem + PAR_OFF + 1280);
     if (tid < 256) bias_l[tid] = a.bias[tid];
     if (MODE2 != 0 && tid < 64) bias2_l[tid] = a.bias2[tid];
-    if (PRO && tid < K) { pro_l[tid] = a.pro_scale[tid]; pro_l[K + tid] = a.pro_shift[tid]; }
+    if ((PRO || PSC) && tid < K) { pro_l[tid] = a.pro_scale[tid]; pro_l[K + tid] = a.pro_shift[tid]; }
+    float* bias_sc_l = reinterpret_cast<float*>(smem + PAR_OFF + 1280 + 4 * K);
+    if (PSC && tid < 256) bias_sc_l[tid] = a.bias_sc[tid];
     // row-wise pass: this thread always owns 16-byte chunk `ch` of a row
     const int ch = tid & 31;
     half8_t sc2 = {}, sh2 = {};
@@ -195,6 +215,10 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         for (int i = 0; i < XI; ++i) {
             const half_t* xs = (m0 + xrow[i] < a.m_total) ? a.in + (size_t)m0 * K + xoff[i] : zero;
             pw_dma16(xs, __builtin_amdgcn_readfirstlane(smem_base + X_OFF + buf * X_BYTES + (i * NW + wave) * 1024));
+            if constexpr (PSC) {
+                const half_t* ss = (m0 + xrow[i] < a.m_total) ? a.x_sc + (size_t)m0 * K + xoff[i] : zero;
+                pw_dma16(ss, __builtin_amdgcn_readfirstlane(smem_base + XS_OFF + buf * X_BYTES + (i * NW + wave) * 1024));
+            }
         }
         if constexpr (RES) {
             // shortcut rows: chunk c = it*512 + tid (row c/32, 16-byte column c%32) lands at c*16, i.e. every
@@ -232,11 +256,11 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         prev_full = m0 + TN <= a.m_total;
 
         // ---- GEMM 1: [256 x 64] x [64 x 64 pixels] ---------------------------------------------
-        floatx16 acc[NI], acc2;
+        floatx16 acc[NI], acc2, accs[NI];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) acc[i][e] = 0.f;
+            for (int i = 0; i < NI; ++i) { acc[i][e] = 0.f; accs[i][e] = 0.f; }
             acc2[e] = 0.f;
         }
         const char* xl = smem + X_OFF + buf * X_BYTES;
@@ -255,6 +279,16 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
             for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][kk], bf, acc[i], 0, 0, 0);
             if constexpr (MODE2 == 1) {
                 if (wave < 4) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[kk], bf, acc2, 0, 0, 0);
+            }
+            if constexpr (PSC) {
+                // projection shortcut on the pre-activated unit input (same pixels, same k step)
+                half8_t bs = *reinterpret_cast<const half8_t*>(smem + XS_OFF + buf * X_BYTES + (kk >> 2) * SL_BYTES + brow * 128 + ((chunk ^ pw_swz(brow)) << 4));
+                const half8_t s = *reinterpret_cast<const half8_t*>(pro_l + kk * 16 + frag_half * 8);
+                const half8_t b = *reinterpret_cast<const half8_t*>(pro_l + K + kk * 16 + frag_half * 8);
+                const half8_t z = {};
+                bs = __builtin_elementwise_max(bs * s + b, z);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) accs[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsf[i][kk], bs, accs[i], 0, 0, 0);
             }
         }
         if constexpr (MODE2 == 1) {
@@ -285,6 +319,14 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
                 half4_t hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) hv[e] = (half_t)(acc[i][4 * q + e] + bv[e]);
+                if constexpr (PSC) {
+                    // fp16(shortcut conv + bias) + fp16(conv3 + bias): the fp16 Add of the reference graph (resnet_v2.py:138)
+                    const floatx4 bs = *reinterpret_cast<const floatx4*>(bias_sc_l + col);
+                    half4_t hs;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hs[e] = (half_t)(accs[i][4 * q + e] + bs[e]);
+                    hv = hv + hs;
+                }
                 *reinterpret_cast<half4_t*>(ol + brow * OUT_ROW + col * 2) = hv;
             }
         }
@@ -366,6 +408,7 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
     // built combinations: prologue without shortcut (projection shortcut, pair) / shortcut without prologue (conv3)
     if (mode == 1) return d.c_in == 64 && d.c_out == 320 && d.has_prologue && !d.has_residual;
     if (mode == 2) return d.c_in == 64 && d.c_out == 256 && !d.has_prologue && d.has_residual;
+    if (mode == 3) return d.c_in == 64 && d.c_out == 256 && !d.has_prologue && !d.has_residual;    // + in-launch projection shortcut
     if (d.c_in == 64 && d.c_out == 256) return (d.has_prologue != 0) != (d.has_residual != 0);
     // conv3 (+ shortcut) of blocks 2-4: c_out = 4 * c_in in 256-channel slabs (METRO_PW_MAXK caps c_in for A/B runs)
     static const int maxk = pw_env_int("METRO_PW_MAXK", 512);
@@ -373,13 +416,13 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
            !d.has_prologue && d.has_residual;
 }
 
-template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false>
+template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false, bool PSC = false>
 static int launch_pw(Pw64Args a, hipStream_t stream) {
-    if (note_kernel("conv_pw64<k%d,wm%d%s%s%s%s>", K, WM, PRO ? ",pro" : "", RES ? ",res" : "",
-                    MODE2 == 1 ? ",pair" : MODE2 == 2 ? ",next" : "", RSUB ? ",ressub" : ""))
+    if (note_kernel("conv_pw64<k%d,wm%d%s%s%s%s%s>", K, WM, PRO ? ",pro" : "", RES ? ",res" : "",
+                    MODE2 == 1 ? ",pair" : MODE2 == 2 ? ",next" : "", RSUB ? ",ressub" : "", PSC ? ",projsc" : ""))
         return METRO_OK;
-    auto kern = conv_pw64_kernel<K, WM, PRO, RES, MODE2, RSUB>;
-    constexpr int lds = pw::lds_bytes<K, WM, RES, MODE2>();
+    auto kern = conv_pw64_kernel<K, WM, PRO, RES, MODE2, RSUB, PSC>;
+    constexpr int lds = pw::lds_bytes<K, WM, RES, MODE2, PSC>();
     a.n_tiles = (a.m_total + pw::Lay<K, WM>::TN - 1) / pw::Lay<K, WM>::TN;
     static PerDeviceInt cap;
     int grid_cap = 0;
@@ -395,10 +438,12 @@ static int launch_pw(Pw64Args a, hipStream_t stream) {
 
 int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* ps,
                      const void* pb, const void* res, void* out, hipStream_t stream, const ConvSplit* split,
-                     const ConvFuse2* f2) {
-    const int mode = (f2 != nullptr && f2->w2 != nullptr) ? 2 : (split != nullptr && split->split > 0) ? 1 : 0;
+                     const ConvFuse2* f2, const ConvProjSc* psc) {
+    const bool proj = psc != nullptr && psc->x != nullptr;
+    const int mode = (f2 != nullptr && f2->w2 != nullptr) ? (proj ? 3 : 2) : (split != nullptr && split->split > 0) ? 1 : 0;
+    if (proj && mode != 3) { set_error("conv_pw64: the in-launch projection shortcut exists for conv3 + next conv1 only"); return METRO_ERR_INVALID_ARG; }
     if (!conv_pw64_supported(d, mode) || (mode == 1 && !(split->split == 256 && split->c_out2 == 64 && split->relu2 == 1)) ||
-        (mode == 2 && f2->c2 != 64)) {
+        (mode >= 2 && f2->c2 != 64)) {
         set_error("conv_pw64: unsupported layer");
         return METRO_ERR_INVALID_ARG;
     }
@@ -411,6 +456,7 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
     a.residual = d.has_residual ? static_cast<const half_t*>(res) : nullptr;
     a.out = static_cast<half_t*>(out);
     a.w2 = nullptr; a.bias2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out2 = nullptr;
+    a.x_sc = nullptr; a.w_sc = nullptr; a.bias_sc = nullptr;
     a.m_total = d.n * d.h_out * d.w_out;
     a.n_tiles = 0;
     a.c_out = mode == 1 ? 256 : d.c_out;
@@ -421,10 +467,15 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
         a.w2 = a.w + 256 * 64; a.bias2 = bias + 256; a.out2 = static_cast<half_t*>(split->out2);
         return launch_pw<64, 4, true, false, 1>(a, stream);
     }
-    if (mode == 2) {
+    if (mode >= 2) {
         a.w2 = static_cast<const half_t*>(f2->w2); a.bias2 = f2->bias2;
         a.scale2 = static_cast<const half_t*>(f2->scale2); a.shift2 = static_cast<const half_t*>(f2->shift2);
         a.out2 = static_cast<half_t*>(f2->out2);
+        if (mode == 3) {
+            a.x_sc = static_cast<const half_t*>(psc->x); a.w_sc = static_cast<const half_t*>(psc->w_sc); a.bias_sc = psc->bias_sc;
+            a.pro_scale = static_cast<const half_t*>(psc->pro_scale); a.pro_shift = static_cast<const half_t*>(psc->pro_shift);
+            return launch_pw<64, 4, false, false, 2, false, true>(a, stream);
+        }
         return launch_pw<64, 4, false, true, 2>(a, stream);
     }
     if (d.c_in == 512) return launch_pw<512, 8, false, true, 0>(a, stream);

@@ -158,6 +158,27 @@ struct ConvFuse2 {
     int c2 = 0;
 };
 
+// conv1 of the SAME unit in front of a 64 -> 64 3x3 (conv3x3_c64.hip PRE1; block1/unit_1, whose input has 64 channels):
+// t1 = relu(W1 * relu(x * scale + shift) + bias1) is computed on the LDS-resident slab (reference resnet_v2.py:119,127-128)
+struct ConvPre1 {
+    const void* w1 = nullptr;         // fp16 [64][64], BN-folded
+    const float* bias1 = nullptr;     // [64]
+    const void* pro_scale = nullptr;  // fp16 [64] pre-activation BN of the unit
+    const void* pro_shift = nullptr;
+    void* t1_dump = nullptr;          // optional: conv1's output fp16 [pixels][64] (layer dumps for the tests; NULL in the product path)
+};
+
+// Projection shortcut of the unit computed INSIDE its conv3 launch (conv_pw64.hip PSC; block1/unit_1): shortcut =
+// fp16(Wsc * relu(x * scale + shift) + bias_sc) from the unit's 64-channel input x (reference resnet_v2.py:119,122-125),
+// added to fp16(conv3 + bias) in fp16 like the reference graph (:138) -- the shortcut tensor never exists in HBM
+struct ConvProjSc {
+    const void* x = nullptr;          // fp16 [pixels][64]: the unit's raw input
+    const void* w_sc = nullptr;       // fp16 [256][64]
+    const float* bias_sc = nullptr;   // [256]
+    const void* pro_scale = nullptr;  // fp16 [64]
+    const void* pro_shift = nullptr;
+};
+
 struct ConvArgs {
     int split, c_out2, relu2;   // see ConvSplit (0 = plain convolution)
     int n, h_in, w_in, c_in, in_pix_stride;
@@ -192,7 +213,8 @@ int launch_conv_f16(const MetroConvDesc& d, const void* in, const void* w, const
 bool conv_f16_dma_supported(const MetroConvDesc& d);
 int launch_conv_f16_dma(const MetroConvDesc& d, const void* in, const void* w, const float* bias,
                         const void* pro_scale, const void* pro_shift, const void* residual, void* out,
-                        hipStream_t stream, const ConvSplit* split = nullptr, const ConvFuse2* fuse2 = nullptr);
+                        hipStream_t stream, const ConvSplit* split = nullptr, const ConvFuse2* fuse2 = nullptr,
+                        const ConvProjSc* psc = nullptr);
 bool conv_f16_fuse2_supported(const MetroConvDesc& d, int c2);
 // 256 x 256 x 64 GEMM with the 8-phase two-wave-group schedule (conv_gemm8p.hip): deep-K 1x1 layers with >= 256 tiles
 bool conv_gemm8p_shape_ok(const MetroConvDesc& d, const ConvSplit* split);      // what the kernel can run
@@ -204,7 +226,7 @@ int launch_conv_gemm8p(const MetroConvDesc& d, const void* in, const void* w, co
 bool conv_pw64_supported(const MetroConvDesc& d, int mode);
 int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* pro_scale,
                      const void* pro_shift, const void* residual, void* out, hipStream_t stream,
-                     const ConvSplit* split, const ConvFuse2* fuse2);
+                     const ConvSplit* split, const ConvFuse2* fuse2, const ConvProjSc* psc = nullptr);
 // stem 7x7/2 conv + zero-padded 3x3/2 max-pool in one persistent kernel (stem_pool_f16.hip); input is the
 // bordered 4-channel fp16 image of launch_prep_input_f16, weights packed [64][7][8][4]
 bool stem_pool_f16_supported(int side, int base_width);
@@ -216,7 +238,8 @@ int launch_stem_pool_f32in(const float* images, const void* w, const float* bias
                            hipStream_t stream);
 // persistent weight-resident 3x3 for the 64 -> 64 channel layers (conv3x3_c64.hip)
 bool conv3x3_c64_supported(const MetroConvDesc& d);
-int launch_conv3x3_c64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out, hipStream_t stream);
+int launch_conv3x3_c64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out, hipStream_t stream,
+                       const ConvPre1* pre1 = nullptr);
 // 3x3 stride-1 convs with tap reuse from an LDS-resident activation slab
 bool conv3x3_slab_supported(const MetroConvDesc& d);
 int launch_conv3x3_slab(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out,

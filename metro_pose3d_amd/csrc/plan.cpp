@@ -87,6 +87,11 @@ struct Layer {
     int split, c_out2, relu2, out2_slot;
     // conv3 of unit u + conv1 of unit u+1 (ConvFuse2): parameter indices of the second GEMM, -1 = none
     int f2_w, f2_bias, f2_scale, f2_shift, f2_c2;
+    // block1/unit_1 in two launches (round 3): conv1 fused in FRONT of conv2 (conv3x3_c64 PRE1: parameter indices of conv1 and of the
+    // unit's pre-activation, -1 = none) and the projection shortcut computed INSIDE the conv3 launch (conv_pw64 PSC: its
+    // parameters and the slot of the unit's input)
+    int p1_w, p1_bias, p1_scale, p1_shift;
+    int psc_w, psc_bias, psc_scale, psc_shift, psc_slot;
     int stem_pool;        // stem conv + max-pool in one launch (the layer's output is the pooled tensor)
     int head_fused;       // logits layer: GEMM + per-joint softmax statistics in one launch (head_f16.hip); the
                           // soft-argmax layer behind it then only finalizes
@@ -165,7 +170,7 @@ struct Builder {
                   int out_dtype, int in_dtype) {
         Layer L;
         memset(&L, 0, sizeof(L));
-        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE;
         L.kind = LK_CONV;
         const bool fast = p->fast;
         const int wdt = fast ? METRO_F16 : METRO_F64;
@@ -207,7 +212,7 @@ struct Builder {
                                 int c_sc, int cb, int adt) {
         Layer L;
         memset(&L, 0, sizeof(L));
-        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE;
         L.kind = LK_CONV;
         MetroConvDesc& cd = L.cd;
         cd.h_in = cd.w_in = side; cd.c_in = c_in; cd.in_pix_stride = c_in;
@@ -262,6 +267,42 @@ struct Builder {
         p->flops_per_image += flops;
     }
 
+    // conv1 of the unit (1x1, cb outputs, folded BN + ReLU, on the pre-activated unit input) fused in FRONT of the conv2 layer
+    // just added, whose input becomes the unit's raw input (reference resnet_v2.py:119,127-132).
+    void fuse_conv1_in_front(const std::string& un, const std::string& sc, int in_slot, int side, int c_in, int cb) {
+        Layer& L = p->layers.back();
+        const std::string conv_var = root + "/" + sc + "/conv1";
+        const std::string bn_var = conv_var + "/BatchNorm";
+        const std::string pv = root + "/" + sc + "/preact";
+        L.p1_w = add_param(un + "/conv1/W", METRO_PARAM_CONV_W, conv_var, bn_var, METRO_F16, cb, 1, 1, c_in, 1, c_in);
+        L.p1_bias = add_param(un + "/conv1/bias", METRO_PARAM_BIAS, conv_var, bn_var, METRO_F32, cb, 1, 1, 1, 1, 1);
+        L.p1_scale = add_param(un + "/conv1/pro_scale", METRO_PARAM_PRO_SCALE, "", pv, METRO_F16, c_in, 1, 1, 1, 1, 1);
+        L.p1_shift = add_param(un + "/conv1/pro_shift", METRO_PARAM_PRO_SHIFT, "", pv, METRO_F16, c_in, 1, 1, 1, 1, 1);
+        L.in_slot = in_slot;
+        const double flops = 2.0 * side * side * (double)cb * c_in;
+        snprintf(L.info.name, sizeof(L.info.name), "%s/conv1+conv2", un.c_str());
+        L.info.flops_per_image += flops;
+        L.info.fused_flags |= METRO_FUSED_CONV1_IN_FRONT;
+        p->flops_per_image += flops;
+    }
+
+    // The unit's projection shortcut (1x1, c_out outputs, bias, on the pre-activated unit input) computed inside the conv3
+    // layer just added instead of being read from a tensor (reference resnet_v2.py:119,122-125,138).
+    void fuse_projection_shortcut(const std::string& un, const std::string& sc, int x_slot, int side, int c_in, int c_out) {
+        Layer& L = p->layers.back();
+        const std::string conv_var = root + "/" + sc + "/shortcut";
+        const std::string pv = root + "/" + sc + "/preact";
+        L.psc_w = add_param(un + "/shortcut/W", METRO_PARAM_CONV_W, conv_var, "", METRO_F16, c_out, 1, 1, c_in, 1, c_in);
+        L.psc_bias = add_param(un + "/shortcut/bias", METRO_PARAM_BIAS, conv_var, "", METRO_F32, c_out, 1, 1, 1, 1, 1);
+        L.psc_scale = add_param(un + "/shortcut/pro_scale", METRO_PARAM_PRO_SCALE, "", pv, METRO_F16, c_in, 1, 1, 1, 1, 1);
+        L.psc_shift = add_param(un + "/shortcut/pro_shift", METRO_PARAM_PRO_SHIFT, "", pv, METRO_F16, c_in, 1, 1, 1, 1, 1);
+        L.psc_slot = x_slot;
+        const double flops = 2.0 * side * side * (double)c_out * c_in;
+        L.info.flops_per_image += flops;
+        L.info.fused_flags |= METRO_FUSED_PROJECTION_SHORTCUT;
+        p->flops_per_image += flops;
+    }
+
     void fill_info(Layer& L, const std::string& lname, double flops) {
         MetroLayerInfo& I = L.info;
         snprintf(I.name, sizeof(I.name), "%s", lname.c_str());
@@ -304,7 +345,7 @@ int build_plan(MetroPlan* p) {
     if (fast) {
         Layer L;
         memset(&L, 0, sizeof(L));
-        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE;
         L.kind = LK_PREP;
         L.cd.h_in = L.cd.w_in = side; L.cd.c_in = 3;
         L.cd.h_out = side + 6; L.cd.w_out = side + 8; L.cd.c_out = 4; L.cd.out_dtype = METRO_F16;
@@ -321,7 +362,7 @@ int build_plan(MetroPlan* p) {
         // the 8th pixel and the 4th channel).
         Layer S;
         memset(&S, 0, sizeof(S));
-        S.f2_w = S.f2_bias = S.f2_scale = S.f2_shift = -1;
+        S.f2_w = S.f2_bias = S.f2_scale = S.f2_shift = -1; S.p1_w = S.p1_bias = S.p1_scale = S.p1_shift = -1; S.psc_w = S.psc_bias = S.psc_scale = S.psc_shift = -1; S.psc_slot = S_NONE;
         S.kind = LK_CONV;
         MetroConvDesc& cd = S.cd;
         cd.h_in = side + 6; cd.w_in = side + 8; cd.c_in = 32; cd.in_pix_stride = 4;
@@ -357,7 +398,7 @@ int build_plan(MetroPlan* p) {
     if (!fused_stem_pool) {
         Layer L;
         memset(&L, 0, sizeof(L));
-        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE;
         L.kind = LK_POOL;
         L.cd.h_in = L.cd.w_in = s2; L.cd.c_in = bw; L.cd.h_out = L.cd.w_out = s4; L.cd.c_out = bw;
         L.cd.kh = L.cd.kw = 3; L.cd.stride = 2; L.cd.dilation = 1; L.cd.pad_top = L.cd.pad_left = 1;
@@ -421,9 +462,26 @@ int build_plan(MetroPlan* p) {
                 probe.out_dtype = probe.in_dtype = METRO_F16; probe.res_stride = 1;
                 pw_pair = conv_pw64_supported(probe, 1);
             }
-            const bool fuse_pair = fast && project && s == 1 && cout % 256 == 0 && cur_c % 64 == 0 &&
+            // block1/unit_1 (64-channel input): conv1 in front of conv2 inside the weight-resident 3x3 kernel, the projection
+            // shortcut inside the conv3 (+ next conv1) launch: two launches, no shortcut / t1 tensors.  The choice must hold for
+            // EVERY batch the plan may run (the layer list is fixed): probed at n = 1.
+            bool unit_fused = false;
+            if (fast && project && s == 1 && r == 1 && cur_c == 64 && cb == 64 && cout == 256 && u < n_units[b] && !conv1_done &&
+                tuning_knob("METRO_UNIT1_FUSED", 1)) {
+                MetroConvDesc c2, c3;
+                memset(&c2, 0, sizeof(c2));
+                c2.n = 1; c2.h_in = c2.w_in = c2.h_out = c2.w_out = cur_side; c2.c_in = c2.in_pix_stride = c2.c_out = 64;
+                c2.kh = c2.kw = 3; c2.stride = 1; c2.dilation = 1; c2.pad_top = c2.pad_left = 1; c2.relu = 1;
+                c2.out_dtype = c2.in_dtype = METRO_F16; c2.res_stride = 1;
+                c3 = c2;
+                c3.kh = c3.kw = 1; c3.pad_top = c3.pad_left = 0; c3.relu = 0; c3.c_out = 256;
+                unit_fused = conv3x3_c64_supported(c2) && conv_pw64_supported(c3, 3);
+            }
+            const bool fuse_pair = fast && project && s == 1 && cout % 256 == 0 && cur_c % 64 == 0 && !unit_fused &&
                                    ((cb % 128 == 0 && cout <= 1024) || pw_pair);
-            if (conv1_done) {
+            if (unit_fused) {
+                // conv1 runs inside the conv2 launch below
+            } else if (conv1_done) {
                 conv1_done = false;       // S_T1 already holds relu(bn(conv1(preact(x))))
             } else if (fuse_pair) {
                 const int pst = B.add_shortcut_conv1_pair(un, sc, cur, cur_side, cur_c, cout, cb, adt);
@@ -444,8 +502,13 @@ int build_plan(MetroPlan* p) {
                                                           : (k_eff - 1) / 2;
             B.add_conv(un + "/conv2", sc + "/conv2", sc + "/conv2/BatchNorm", "", S_T1, S_T2, S_NONE,
                        cur_side, cb, side_out, cb, 3, s, r, pad_beg, true, 0, 1, 0, adt, adt);
+            if (unit_fused) B.fuse_conv1_in_front(un, sc, cur, cur_side, cur_c, cb);
             // conv3 + bias + shortcut (resnet_v2.py:134-138)
-            if (project)
+            if (unit_fused) {
+                B.add_conv(un + "/conv3", sc + "/conv3", "", "", S_T2, nxt, S_NONE, side_out, cb, side_out, cout, 1, 1, 1, 0, false,
+                           0, 1, 0, adt, adt);
+                B.fuse_projection_shortcut(un, sc, cur, cur_side, cur_c, cout);
+            } else if (project)
                 B.add_conv(un + "/conv3", sc + "/conv3", "", "", S_T2, nxt, S_SC, side_out, cb, side_out,
                            cout, 1, 1, 1, 0, false, side_out, 1, 0, adt, adt);
             else
@@ -455,7 +518,7 @@ int build_plan(MetroPlan* p) {
             if (fast && u < n_units[b] && s == 1) {
                 MetroConvDesc probe = p->layers.back().cd;
                 probe.n = 1;
-                if (conv_f16_fuse2_supported(probe, cb)) {
+                if (conv_f16_fuse2_supported(probe, cb) || unit_fused) {
                     const std::string un2 = "block" + std::to_string(b + 1) + "/unit_" + std::to_string(u + 1);
                     B.fuse_next_conv1(un2, un2 + "/bottleneck_v2", side_out, cout, cb);
                     conv1_done = true;
@@ -479,7 +542,7 @@ int build_plan(MetroPlan* p) {
     {
         Layer L;
         memset(&L, 0, sizeof(L));
-        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1;
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE;
         L.kind = LK_SOFTARGMAX;
         L.cd.h_in = L.cd.w_in = cur_side; L.cd.c_in = c_head; L.cd.h_out = 1; L.cd.w_out = sp.n_joints_out;
         L.cd.c_out = 3; L.cd.out_dtype = METRO_F32;
@@ -513,6 +576,10 @@ int build_plan(MetroPlan* p) {
         const bool two = L.kind == LK_CONV && (L.split > 0 || L.f2_w >= 0);
         L.info.out2_offset = two ? p->slot_offset[L.out2_slot] : -1;
         L.info.out2_channels = two ? (L.split > 0 ? L.c_out2 : L.f2_c2) : 0;
+        if (L.p1_w >= 0) {      // conv1+conv2: conv1's output is a DUMP-ONLY second tensor (metro_forward_upto stopping here), not traffic
+            L.info.out2_offset = p->slot_offset[S_T1];
+            L.info.out2_channels = p->params[L.p1_w].c_out;
+        }
         // algorithmic bytes: every tensor the launch touches, once
         const int64_t in_es = L.in_slot == S_IMAGES ? 4 : (L.kind == LK_SOFTARGMAX ? (sp.precision == METRO_PREC_F64 ? 8 : 4)
                                                            : (L.kind == LK_CONV && !fast ? aes : (L.kind == LK_CONV ? 2 : aes)));
@@ -524,6 +591,7 @@ int build_plan(MetroPlan* p) {
         else act += L.info.out_bytes_per_image;
         if (two) act += (int64_t)L.cd.h_out * L.cd.w_out * L.info.out2_channels * es;
         if (L.kind == LK_CONV && L.cd.has_residual) act += (int64_t)L.cd.h_out * L.cd.w_out * L.cd.c_out * es;
+        if (L.psc_w >= 0) act += (int64_t)L.cd.h_out * L.cd.w_out * p->params[L.psc_w].c_in * es;      // the unit input, read for the shortcut
         if (L.head_fused) {       // logits never reach HBM: the launch writes / the finalize reads the per-slab statistics
             const int64_t part = (int64_t)head_f16_slabs(sp.proc_side / sp.stride) * sp.n_joints_head * 5 * 4;
             if (L.kind == LK_CONV) act = (int64_t)L.cd.h_in * L.cd.w_in * L.cd.c_in * 2 + part;
@@ -531,7 +599,8 @@ int build_plan(MetroPlan* p) {
         }
         L.info.algo_act_bytes_per_image = act;
         int64_t pb = 0;
-        for (int idx : {L.p_w, L.p_bias, L.p_scale, L.p_shift, L.f2_w, L.f2_bias, L.f2_scale, L.f2_shift})
+        for (int idx : {L.p_w, L.p_bias, L.p_scale, L.p_shift, L.f2_w, L.f2_bias, L.f2_scale, L.f2_shift, L.p1_w, L.p1_bias, L.p1_scale,
+                        L.p1_shift, L.psc_w, L.psc_bias, L.psc_scale, L.psc_shift})
             if (idx >= 0) pb += p->params[idx].bytes;
         if (L.split > 0) pb += p->params[L.p_w + 1].bytes + p->params[L.p_bias + 1].bytes;   // conv1 rows of a fused pair
         L.info.algo_param_bytes = pb;
@@ -539,8 +608,9 @@ int build_plan(MetroPlan* p) {
     return METRO_OK;
 }
 
-// One layer of the plan at batch n.  `dump_logits`: the one-launch head also writes the fp32 logits tensor (layer dumps).
-int launch_layer(MetroPlan* p, int li, const float* images, int n, float* poses, char* ws, hipStream_t stream, bool dump_logits) {
+// One layer of the plan at batch n.  `dump` (metro_forward_upto stopping at this layer): launches whose intermediate tensors live on
+// chip also write them out -- the fp32 logits of the one-launch head, conv1's output of a conv1+conv2 launch.
+int launch_layer(MetroPlan* p, int li, const float* images, int n, float* poses, char* ws, hipStream_t stream, bool dump) {
     Layer& L = p->layers[li];
     auto slot_ptr = [&](int slot) -> void* {
         if (slot == S_IMAGES) return const_cast<float*>(images);
@@ -557,10 +627,10 @@ int launch_layer(MetroPlan* p, int li, const float* images, int n, float* poses,
             MetroConvDesc cd = L.cd;
             cd.n = n;
             if (p->fast && L.head_fused) {
-                float* dump = dump_logits ? static_cast<float*>(slot_ptr(L.out_slot)) : nullptr;
+                float* logits_dump = dump ? static_cast<float*>(slot_ptr(L.out_slot)) : nullptr;
                 return launch_head_f16(slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)), prm(L.p_scale),
                                        prm(L.p_shift), n, L.cd.c_in, L.cd.c_out, p->spec.n_joints_head, p->spec.depth, L.cd.h_in,
-                                       static_cast<float*>(slot_ptr(S_PART)), dump, stream);
+                                       static_cast<float*>(slot_ptr(S_PART)), logits_dump, stream);
             }
             if (p->fast && L.stem_pool == 2)
                 return launch_stem_pool_f32in(images, prm(L.p_w), static_cast<const float*>(prm(L.p_bias)), slot_ptr(L.out_slot), n,
@@ -579,8 +649,22 @@ int launch_layer(MetroPlan* p, int li, const float* images, int n, float* poses,
                 f2.w2 = prm(L.f2_w); f2.bias2 = static_cast<const float*>(prm(L.f2_bias));
                 f2.scale2 = prm(L.f2_scale); f2.shift2 = prm(L.f2_shift);
                 f2.out2 = slot_ptr(L.out2_slot); f2.c2 = L.f2_c2;
+                ConvProjSc ps;
+                if (L.psc_w >= 0) {
+                    ps.x = slot_ptr(L.psc_slot); ps.w_sc = prm(L.psc_w); ps.bias_sc = static_cast<const float*>(prm(L.psc_bias));
+                    ps.pro_scale = prm(L.psc_scale); ps.pro_shift = prm(L.psc_shift);
+                }
                 return launch_conv_f16_dma(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
-                                           nullptr, nullptr, slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream, nullptr, &f2);
+                                           nullptr, nullptr, slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream, nullptr, &f2,
+                                           L.psc_w >= 0 ? &ps : nullptr);
+            }
+            if (p->fast && L.p1_w >= 0) {
+                ConvPre1 p1;
+                p1.w1 = prm(L.p1_w); p1.bias1 = static_cast<const float*>(prm(L.p1_bias));
+                p1.pro_scale = prm(L.p1_scale); p1.pro_shift = prm(L.p1_shift);
+                p1.t1_dump = dump ? slot_ptr(S_T1) : nullptr;        // conv1's output exists in LDS only; layer dumps get a copy
+                return launch_conv3x3_c64(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
+                                          slot_ptr(L.out_slot), stream, &p1);
             }
             if (p->fast)
                 return launch_conv_f16(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
@@ -619,7 +703,6 @@ int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_
     int st = METRO_OK;
     for (int li = 0; li <= last_layer && st == METRO_OK; ++li) {
         if (ms_out) METRO_HIP_CHECK(hipEventRecord(ev[2 * li], stream));
-        // layer dumps (metro_forward_upto stopping at the one-launch head) also get the fp32 logits tensor
         st = launch_layer(p, li, images, n, poses, ws, stream, li == last_layer && li + 1 < nl);
         if (ms_out) METRO_HIP_CHECK(hipEventRecord(ev[2 * li + 1], stream));
     }
@@ -842,6 +925,35 @@ int metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d_
     f2.w2 = d_w2; f2.bias2 = d_bias2; f2.scale2 = d_scale2; f2.shift2 = d_shift2; f2.out2 = d_out2; f2.c2 = c2;
     return launch_conv_f16_dma(*d, d_in, d_w, d_bias, nullptr, nullptr, d_residual, d_out,
                                static_cast<hipStream_t>(stream), nullptr, &f2);
+}
+
+int metro_conv_f16_conv1_conv2(const MetroConvDesc* d, const void* d_x, const void* d_w1, const float* d_bias1, const void* d_pro_scale,
+                               const void* d_pro_shift, const void* d_w2, const float* d_bias2, void* d_out, void* stream) {
+    int st = validate_conv_desc(d);
+    if (st) return st;
+    METRO_CHECK_ARG(d_x && d_w1 && d_bias1 && d_pro_scale && d_pro_shift && d_w2 && d_bias2 && d_out, "conv_f16_conv1_conv2: NULL tensor pointer");
+    METRO_CHECK_ARG(conv3x3_c64_supported(*d), "conv_f16_conv1_conv2: built for 3x3 stride-1 SAME 64 -> 64 on maps of <= 64 columns that tile into "
+                    "128-pixel row pairs (block1 of the 256-pixel nets)");
+    ConvPre1 p1;
+    p1.w1 = d_w1; p1.bias1 = d_bias1; p1.pro_scale = d_pro_scale; p1.pro_shift = d_pro_shift;
+    return launch_conv3x3_c64(*d, d_x, d_w2, d_bias2, d_out, static_cast<hipStream_t>(stream), &p1);
+}
+
+int metro_conv_f16_next_proj(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias, const void* d_x,
+                             const void* d_w_sc, const float* d_bias_sc, const void* d_pro_scale, const void* d_pro_shift, void* d_out,
+                             const void* d_w2, const float* d_bias2, const void* d_scale2, const void* d_shift2, void* d_out2,
+                             int32_t c2, void* stream) {
+    int st = validate_conv_desc(d);
+    if (st) return st;
+    METRO_CHECK_ARG(d_in && d_w && d_bias && d_x && d_w_sc && d_bias_sc && d_pro_scale && d_pro_shift && d_out && d_w2 && d_bias2 &&
+                        d_scale2 && d_shift2 && d_out2, "conv_f16_next_proj: NULL tensor pointer");
+    METRO_CHECK_ARG(conv_pw64_supported(*d, 3) && c2 == 64, "conv_f16_next_proj: built for 1x1 stride-1 64 -> 256 without prologue / residual, "
+                    "c2 = 64 (block1/unit_1), fp16");
+    ConvFuse2 f2;
+    f2.w2 = d_w2; f2.bias2 = d_bias2; f2.scale2 = d_scale2; f2.shift2 = d_shift2; f2.out2 = d_out2; f2.c2 = c2;
+    ConvProjSc ps;
+    ps.x = d_x; ps.w_sc = d_w_sc; ps.bias_sc = d_bias_sc; ps.pro_scale = d_pro_scale; ps.pro_shift = d_pro_shift;
+    return launch_conv_f16_dma(*d, d_in, d_w, d_bias, nullptr, nullptr, nullptr, d_out, static_cast<hipStream_t>(stream), nullptr, &f2, &ps);
 }
 
 int metro_conv_f16_gemm8p(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,

@@ -82,6 +82,19 @@ def test_planner_agrees_with_oracle_schedule(arch, stride, centered, prec):
             layers[f'{unit}/conv3'] = li
             fused_into[f'{unit.split("/")[0]}/{nxt[:-len("/conv1")]}'] = li
     for u in units:
+        if f'{u.name}/conv1+conv2' in layers:
+            # fp16 plans of full-width block1/unit_1 (64-channel input): conv1 runs on the 3x3 layer's LDS-resident slab and the
+            # projection shortcut inside the conv3 launch -- no conv1 / shortcut / pair layer, no shortcut tensor
+            c12, c3 = layers[f'{u.name}/conv1+conv2'], layers[f'{u.name}/conv3']
+            assert prec == 'f16' and u.c_in == 64 and u.c_out == 256 and u.stride == 1 and u.rate == 1
+            assert not any(f'{u.name}/{k}' in layers for k in ('conv1', 'conv2', 'shortcut', 'shortcut+conv1'))
+            assert c12.fused_flags == _lib.FUSED_CONV1_IN_FRONT and c3.fused_flags == _lib.FUSED_PROJECTION_SHORTCUT
+            assert (c12.kh, c12.stride, c12.dilation, c12.c_in, c12.c_out, c12.h_in, c12.h_out, c12.pad_top, c12.relu) == \
+                (3, 1, 1, u.c_in, u.c_bott, u.side_in, u.side_out, 1, 1)
+            assert abs(c12.flops_per_image - 2.0 * u.side_in ** 2 * u.c_bott * (9 * u.c_bott + u.c_in)) < 1
+            assert (c3.c_in, c3.c_out, c3.has_residual, c3.has_prologue, c3.relu) == (u.c_bott, u.c_out, 0, 0, 0)
+            assert abs(c3.flops_per_image - 2.0 * u.side_in ** 2 * (u.c_out * (u.c_bott + u.c_in) + u.c_bott * u.c_out)) < 1
+            continue
         c2, c3 = (layers[f'{u.name}/conv{i}'] for i in (2, 3))
         if u.name in fused_into:
             host = fused_into[u.name]

@@ -78,6 +78,8 @@ def layer_keys(name):
         return 'pool1', None
     if name in ('conv1', 'pool1', 'logits'):
         return name, None
+    if name.endswith('/conv1+conv2'):                    # conv1 runs on the 3x3 layer's LDS slab; layer dumps get a copy of its output
+        return name[:-len('conv1+conv2')] + 'conv2', name[:-len('conv1+conv2')] + 'conv1'
     if name.endswith('/shortcut+conv1'):
         unit = name[:-len('/shortcut+conv1')]
         return unit + '/shortcut', unit + '/conv1'
@@ -155,6 +157,8 @@ def test_f16_mode_layerwise_against_fp16_oracle(cuda, case):
         assert k1 is not None and k1 in col, f'layer {name!r} has no oracle counterpart'
         got = fetch(i)
         hip[k1] = got
+        if li.fused_flags & _lib.FUSED_CONV1_IN_FRONT:       # the 3x3's reference needs the launch's OWN conv1 output: dumped first
+            hip[k2] = fetch(i, second=True)
         # ---- the oracle function of this tensor on the HIP path's own inputs -------------------------
         ref2 = addend = None
         if k1 == 'pool1':
@@ -171,9 +175,13 @@ def test_f16_mode_layerwise_against_fp16_oracle(cuda, case):
                 ref = f16emu.unit_conv1(unit_input(uname), params, pre)
             elif kind == '/conv2':
                 ref = f16emu.unit_conv2(hip[uname + '/conv1'], params, pre, unit)
+                if li.fused_flags & _lib.FUSED_CONV1_IN_FRONT:   # conv1 of the same launch, held to the model like any conv1
+                    ref2 = f16emu.unit_conv1(unit_input(uname), params, pre)
             else:
                 assert kind == '', k1
-                sc = hip[uname + '/shortcut'] if unit.c_in != unit.c_out else \
+                # the shortcut is a tensor of the plan (projection), or computed by the oracle from the HIP path's own unit input:
+                # identity shortcuts, and the projection computed inside the conv3 launch (METRO_FUSED_PROJECTION_SHORTCUT)
+                sc = hip[uname + '/shortcut'] if uname + '/shortcut' in hip else \
                     f16emu.unit_shortcut(unit_input(uname), params, pre, unit)
                 ref = f16emu.unit_conv3_add(hip[uname + '/conv2'], sc, params, pre)
                 addend = nhwc(sc)

@@ -58,6 +58,8 @@ def test_toy_layerwise(cuda, spec):
             key = {'logits': 'logits', 'conv1': 'conv1', 'pool1': 'pool1', 'conv1+pool1': 'pool1'}.get(name)
             if key is None and (name.endswith('/conv3') or '/conv3+' in name):
                 key = name.split('/conv3')[0]                # unit output = shortcut + conv3
+            elif key is None and name.endswith('/conv1+conv2'):
+                key = name[:-len('conv1+conv2')] + 'conv2'   # conv1 fused in front of conv2 (block1/unit_1 at full width)
             elif key is None and name.endswith(('/conv1', '/conv2')):
                 key = name
             if key is None or key not in col:
@@ -127,13 +129,16 @@ def test_fused_launch_second_outputs(cuda):
             want = torch.relu(pre @ torch.from_numpy(w) + torch.from_numpy((b1 - mu1 * g1).astype(np.float32)).double())
             err = (torch.from_numpy(got2) - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
             assert err <= 4e-3, (name, err)
+        elif name.endswith('/conv1+conv2'):                 # conv1 in front of the 3x3: its output is a dump-only second tensor
+            key2 = name[:-len('conv1+conv2')] + 'conv1'
+            seen.add('conv1+conv2')
         else:
             key2 = name.replace('shortcut+conv1', 'conv1')
             seen.add('shortcut+conv1')
         ref2 = col[key2].permute(0, 2, 3, 1).numpy()
         err = np.abs(got2 - ref2).max() / max(np.abs(ref2).max(), 1e-30)
         assert err <= 3e-2, (name, 'second output', err)
-    assert seen == {'conv3+conv1', 'shortcut+conv1'}
+    assert seen == {'conv3+conv1', 'shortcut+conv1', 'conv1+conv2'}
 
 
 def test_full_rn50_s16_all_modes(cuda):
@@ -275,16 +280,17 @@ def test_race_screen_batch64_persistent_kernels(cuda):
     x = torch.from_numpy(images).to(cuda)
     eng = Engine(spec, params, 'f16', max_batch=64, device=cuda)
     names = [li.name.decode() for li in eng.layer_infos()]
-    picks = [i for i, n in enumerate(names) if n in ('conv1+pool1', 'block1/unit_1/shortcut+conv1', 'block1/unit_1/conv3+unit_2/conv1',
+    picks = [i for i, n in enumerate(names) if n in ('conv1+pool1', 'block1/unit_1/conv1+conv2', 'block1/unit_1/conv3+unit_2/conv1',
+                                                     'block2/unit_1/shortcut+conv1',
                                                      'block1/unit_3/conv3', 'block2/unit_2/conv3', 'block3/unit_2/conv2',
                                                      'block3/unit_3/conv3', 'block4/unit_2/conv3', 'logits',
                                                      'block1/unit_2/conv2',          # conv3x3_c64: persistent, double-buffered slabs
                                                      'block4/unit_1/shortcut')]      # conv_gemm8p: two wave groups, vmcnt(6) ring
-    assert len(picks) == 11
+    assert len(picks) == 12
     ref = eng.forward(x).clone()
     refs = {i: eng.forward_upto(x, i).clone() for i in picks}
     seconds = {i: eng.forward_upto(x, i, second=True).clone() for i in picks if eng.layer_infos()[i].out2_offset >= 0}
-    assert torch.isfinite(ref).all() and len(seconds) == 2
+    assert torch.isfinite(ref).all() and len(seconds) == 3
     junk = torch.empty(256 << 20, dtype=torch.uint8, device=cuda)
     for it in range(12):
         if it % 2 == 0:

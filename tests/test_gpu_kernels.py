@@ -214,6 +214,95 @@ def test_conv_f16_next(lib, cuda, shape):
     assert np.abs(got2 - want2).max() <= 2e-3 * np.abs(want2).max()
 
 
+@pytest.mark.parametrize('shape', [(21, 64), (5, 32), (9, 16), (1, 64)], ids=['many_tiles_64map', '32map', '16map', 'one_image'])
+def test_conv_f16_conv1_conv2(lib, cuda, shape):
+    """conv1 (1x1 on relu(x * s + b), folded BN + ReLU) fused in FRONT of the weight-resident 3x3 (conv3x3_c64 PRE1; reference
+    resnet_v2.py:119,127-132): every element against fp64 with ONE fp16 rounding of conv1's output (it lives in LDS as fp16).
+    Image borders inside a block's tile range (taps outside the image read zeros of t1, NOT conv1 of a zero input), halo rows
+    recomputed by both tiles that share them; repeated launches are bit-identical."""
+    n, h = shape
+    rng = np.random.default_rng(zlib.crc32(repr(('c1c2',) + shape).encode()))
+    x = rng.standard_normal((n, h, h, 64)).astype(np.float16)
+    w1 = (rng.standard_normal((64, 64)) * np.sqrt(2.0 / 64)).astype(np.float16)
+    b1 = (rng.standard_normal(64) * 0.3 + 0.2).astype(np.float32)          # conv1 of a zero input is far from zero
+    ps = rng.uniform(0.5, 1.5, 64).astype(np.float16)
+    pb = (rng.standard_normal(64) * 0.2 + 0.3).astype(np.float16)
+    w2 = (rng.standard_normal((64, 3, 3, 64)) * np.sqrt(2.0 / 576)).astype(np.float16)
+    b2 = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    d = H.conv_desc(n, h, 64, h, 64, 3, 1, 1, 1, relu=True, in_dtype=_lib.METRO_F16)
+    t = [_dev(x, cuda, np.float16), _dev(w1, cuda, np.float16), _dev(b1, cuda, np.float32), _dev(ps, cuda, np.float16),
+         _dev(pb, cuda, np.float16), _dev(w2, cuda, np.float16), _dev(b2, cuda, np.float32)]
+    outs = []
+    for rep in range(3):
+        out = torch.full((n, h, h, 64), float('nan'), dtype=torch.float16, device=cuda)
+        check(lib.metro_conv_f16_conv1_conv2(C.byref(d), *[H.ptr(a) for a in t], H.ptr(out), None), 'metro_conv_f16_conv1_conv2')
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    xin = np.maximum((x.astype(np.float64) * ps.astype(np.float64) + pb.astype(np.float64)).astype(np.float16).astype(np.float64), 0)
+    t1 = np.maximum(xin @ w1.astype(np.float64).T + b1.astype(np.float64), 0).astype(np.float16)
+    ref = H.ref_conv_nhwc(t1, w2, b2, 1, 1, 1, h, relu=True).numpy()
+    got = outs[0].astype(np.float64)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+    # and it IS the two separate launches: conv1 through the generic kernel, then the plain weight-resident 3x3 -- same bits
+    d1 = H.conv_desc(n, h, 64, h, 64, 1, prologue=True, relu=True, in_dtype=_lib.METRO_F16)
+    sep1 = H.run_conv_f16(lib, cuda, d1, x, w1.reshape(64, 1, 1, 64), b1, pro=(ps, pb))
+    sep = H.run_conv_f16(lib, cuda, d, sep1, w2, b2)
+    assert (sep == outs[0]).mean() > 0.995 and np.abs(sep.astype(np.float64) - got).max() <= 2e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('shape', [(3, 7), (2, 8), (12, 64)], ids=['ragged', 'small', 'many_tiles'])
+def test_conv_f16_next_proj(lib, cuda, shape):
+    """conv3 + the unit's PROJECTION shortcut computed in the launch + conv1 of the next unit (conv_pw64 PSC; reference
+    resnet_v2.py:119,122-125,134-138 then :119,127-128 of unit u+1): first output against fp64 with one rounding per addend
+    (fp16(conv3 + b) + fp16(shortcut conv + b), the fp16 Add of the graph), second output from the kernel's own first output;
+    and the same bits as metro_conv_f16_next fed the separately computed shortcut tensor."""
+    n, h = shape
+    rng = np.random.default_rng(zlib.crc32(repr(('nextproj',) + shape).encode()))
+    t2in, w3, b3 = _mk(rng, n, h, 64, 256, 1)
+    xu = rng.standard_normal((n, h, h, 64)).astype(np.float16)
+    wsc = (rng.standard_normal((256, 64)) * np.sqrt(2.0 / 64)).astype(np.float16)
+    bsc = (rng.standard_normal(256) * 0.1).astype(np.float32)
+    ps = rng.uniform(0.5, 1.5, 64).astype(np.float16)
+    pb = (rng.standard_normal(64) * 0.2).astype(np.float16)
+    w2 = (rng.standard_normal((64, 256)) * np.sqrt(2.0 / 256)).astype(np.float16)
+    b2 = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    sc2 = rng.uniform(0.5, 1.5, 256).astype(np.float16)
+    sh2 = (rng.standard_normal(256) * 0.2).astype(np.float16)
+    d = H.conv_desc(n, h, 64, h, 256, 1, in_dtype=_lib.METRO_F16)
+    f16, f32 = np.float16, np.float32
+    t = [_dev(t2in, cuda, f16), _dev(w3, cuda, f16), _dev(b3, cuda, f32), _dev(xu, cuda, f16), _dev(wsc, cuda, f16), _dev(bsc, cuda, f32),
+         _dev(ps, cuda, f16), _dev(pb, cuda, f16)]
+    t_next = [_dev(w2, cuda, f16), _dev(b2, cuda, f32), _dev(sc2, cuda, f16), _dev(sh2, cuda, f16)]
+    out = torch.full((n, h, h, 256), float('nan'), dtype=torch.float16, device=cuda)
+    out2 = torch.full((n, h, h, 64), float('nan'), dtype=torch.float16, device=cuda)
+    check(lib.metro_conv_f16_next_proj(C.byref(d), *[H.ptr(a) for a in t], H.ptr(out), *[H.ptr(a) for a in t_next], H.ptr(out2), 64, None),
+          'metro_conv_f16_next_proj')
+    torch.cuda.synchronize()
+    got, got2 = out.cpu().double().numpy(), out2.cpu().double().numpy()
+    assert np.isfinite(got).all() and np.isfinite(got2).all()
+    conv3 = H.ref_conv_nhwc(t2in.astype(f16), w3.astype(f16), b3, 1, 1, 0, h).numpy().astype(f16).astype(np.float64)
+    xin = np.maximum((xu.astype(np.float64) * ps.astype(np.float64) + pb.astype(np.float64)).astype(f16).astype(np.float64), 0)
+    sc = (xin @ wsc.astype(np.float64).T + bsc.astype(np.float64)).astype(f16).astype(np.float64)
+    ref = conv3 + sc
+    assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()
+    pre = np.maximum(np.float16(got * sc2.astype(np.float64) + sh2.astype(np.float64)), 0).astype(np.float64)
+    want2 = np.maximum(pre @ w2.astype(np.float64).T + b2.astype(np.float64), 0)
+    assert np.abs(got2 - want2).max() <= 2e-3 * np.abs(want2).max()
+    # the shortcut as its own launch, then metro_conv_f16_next on that tensor: the same arithmetic, tensor for tensor
+    dsc = H.conv_desc(n, h, 64, h, 256, 1, prologue=True, in_dtype=_lib.METRO_F16)
+    sc_t = H.run_conv_f16(lib, cuda, dsc, xu, wsc.reshape(256, 1, 1, 64), bsc, pro=(ps, pb))
+    dn = H.conv_desc(n, h, 64, h, 256, 1, residual=True, res_h=h, in_dtype=_lib.METRO_F16)
+    o1 = torch.full_like(out, float('nan'))
+    o2 = torch.full_like(out2, float('nan'))
+    tsc = _dev(sc_t, cuda, f16)
+    check(lib.metro_conv_f16_next(C.byref(dn), H.ptr(t[0]), H.ptr(t[1]), H.ptr(t[2]), H.ptr(tsc), H.ptr(o1), *[H.ptr(a) for a in t_next],
+                                  H.ptr(o2), 64, None), 'metro_conv_f16_next')
+    torch.cuda.synchronize()
+    assert torch.equal(o1, out) and torch.equal(o2, out2), 'in-launch projection shortcut vs the shortcut tensor of a separate launch'
+
+
 @pytest.mark.parametrize('n,side', [(2, 64), (3, 96), (9, 256)])
 def test_stem_pool_f16(lib, cuda, n, side):
     """Stem 7x7/2 + zero-padded 3x3/2 max-pool in one launch against torch fp64 on the same fp16 operands

@@ -232,6 +232,18 @@ def _conv(lib, cuda, li, n, gen, rng, dev, kid, name):
         tr, rb = _periodic(gen, n, (res_h, res_h, c_out), cuda)
     out = torch.full((n, h_out, h_out, c1), float('nan'), dtype=torch.float32 if f32out else torch.float16, device=cuda)
     out2 = None
+    if li.fused_flags & _lib.FUSED_CONV1_IN_FRONT:
+        return _conv1_conv2(lib, cuda, li, n, d, x, xb, tw, tb, w, b, out, rng, dev, kid)
+    psc = None
+    if li.fused_flags & _lib.FUSED_PROJECTION_SHORTCUT:
+        assert nxt, 'the in-launch projection shortcut exists in the conv3 + next conv1 launch only'
+        cx = 64                                   # the unit's raw input (block1/unit_1: the pooled stem output)
+        xs, xsb = _periodic(gen, n, (h_out, h_out, cx), cuda)
+        wsc = (rng.standard_normal((c1, cx)) * np.sqrt(2.0 / cx)).astype(np.float16)
+        bsc = (rng.standard_normal(c1) * 0.1).astype(np.float32)
+        psc_s = rng.uniform(0.5, 1.5, cx).astype(np.float16)
+        psc_b = (rng.standard_normal(cx) * 0.2).astype(np.float16)
+        psc = [xs, dev(wsc, np.float16), dev(bsc, np.float32), dev(psc_s, np.float16), dev(psc_b, np.float16)]
     if pair:
         out2 = torch.full((n, h_out, h_out, li.out2_channels), float('nan'), dtype=torch.float16, device=cuda)
         check(lib.metro_conv_f16_pair(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(out), c1, H.ptr(out2), None),
@@ -244,8 +256,13 @@ def _conv(lib, cuda, li, n, gen, rng, dev, kid, name):
         sh2 = (rng.standard_normal(c1) * 0.2).astype(np.float16)
         t2 = [dev(w2, np.float16), dev(b2, np.float32), dev(sc2, np.float16), dev(sh2, np.float16)]
         out2 = torch.full((n, h_out, h_out, c2), float('nan'), dtype=torch.float16, device=cuda)
-        check(lib.metro_conv_f16_next(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(tr), H.ptr(out), H.ptr(t2[0]), H.ptr(t2[1]),
-                                      H.ptr(t2[2]), H.ptr(t2[3]), H.ptr(out2), c2, None), 'metro_conv_f16_next')
+        if psc is not None:
+            check(lib.metro_conv_f16_next_proj(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(psc[0]), H.ptr(psc[1]), H.ptr(psc[2]),
+                                               H.ptr(psc[3]), H.ptr(psc[4]), H.ptr(out), H.ptr(t2[0]), H.ptr(t2[1]), H.ptr(t2[2]),
+                                               H.ptr(t2[3]), H.ptr(out2), c2, None), 'metro_conv_f16_next_proj')
+        else:
+            check(lib.metro_conv_f16_next(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(tr), H.ptr(out), H.ptr(t2[0]), H.ptr(t2[1]),
+                                          H.ptr(t2[2]), H.ptr(t2[3]), H.ptr(out2), c2, None), 'metro_conv_f16_next')
     else:
         check(lib.metro_conv_f16(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr), H.ptr(out), None),
               'metro_conv_f16')
@@ -267,8 +284,31 @@ def _conv(lib, cuda, li, n, gen, rng, dev, kid, name):
     if rb is not None:        # fp16(conv + bias), then the fp16 Add of the (sub-sampled, shifted) shortcut
         r = rb.astype(np.float64)[:, li.res_offset::li.res_stride, li.res_offset::li.res_stride][:, :h_out, :h_out]
         ref = ref.astype(np.float16).astype(np.float64) + r
+    if psc is not None:       # fp16(conv3 + bias) + fp16(Wsc . fp16(relu(x * s + b)) + bias_sc): the fp16 Add of resnet_v2.py:138
+        xin_s = np.maximum((xsb.astype(np.float64) * psc_s.astype(np.float64) + psc_b.astype(np.float64)).astype(np.float16).astype(np.float64), 0)
+        sc = (xin_s @ wsc.astype(np.float64).T + bsc.astype(np.float64)).astype(np.float16).astype(np.float64)
+        ref = ref.astype(np.float16).astype(np.float64) + sc
     _close(got, ref, kid, tol=2e-5 if f32out else 2e-3)
     if nxt:
         pre = np.maximum((got * sc2.astype(np.float64) + sh2.astype(np.float64)).astype(np.float16).astype(np.float64), 0)
         want2 = np.maximum(pre @ w2.astype(np.float64).T + b2.astype(np.float64), 0)
         _close(out2[:p].cpu().numpy(), want2, kid + ' (second output)')
+
+
+def _conv1_conv2(lib, cuda, li, n, d, x, xb, tw2, tb2, w2, b2, out, rng, dev, kid):
+    """conv1 (1x1 on the pre-activated input, folded BN + ReLU) fused in front of the 3x3: t1 is rounded to fp16 once (in LDS)."""
+    c = li.c_in
+    w1 = (rng.standard_normal((li.c_out, c)) * np.sqrt(2.0 / c)).astype(np.float16)
+    b1 = (rng.standard_normal(li.c_out) * 0.1).astype(np.float32)
+    ps = rng.uniform(0.5, 1.5, c).astype(np.float16)
+    pb = (rng.standard_normal(c) * 0.2).astype(np.float16)
+    t = [dev(w1, np.float16), dev(b1, np.float32), dev(ps, np.float16), dev(pb, np.float16)]
+    check(lib.metro_conv_f16_conv1_conv2(C.byref(d), H.ptr(x), H.ptr(t[0]), H.ptr(t[1]), H.ptr(t[2]), H.ptr(t[3]), H.ptr(tw2), H.ptr(tb2),
+                                         H.ptr(out), None), 'metro_conv_f16_conv1_conv2')
+    torch.cuda.synchronize()
+    assert _noted(lib) == [kid], f'the entry point launched {_noted(lib)}, the plan names {kid}'
+    _assert_periodic(out, n, kid)
+    xin = np.maximum((xb.astype(np.float64) * ps.astype(np.float64) + pb.astype(np.float64)).astype(np.float16).astype(np.float64), 0)
+    t1 = np.maximum(xin @ w1.astype(np.float64).T + b1.astype(np.float64), 0).astype(np.float16)
+    ref = H.ref_conv_nhwc(t1, w2, b2, 1, 1, 1, li.h_out, relu=True).numpy()
+    _close(out[:xb.shape[0]].cpu().numpy(), ref, kid)
