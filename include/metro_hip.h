@@ -232,6 +232,12 @@ int  metro_conv_f16_next_proj(const MetroConvDesc* d, const void* d_in, const vo
 int  metro_conv_f16_gemm8p(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                            const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
                            int32_t split, void* d_out2, void* stream);
+/* The same contract and shapes on the FOUR-wave form of that GEMM (conv_gemm4w.hip: 128 x 128 wave tiles, register-staged
+ * operands, one barrier per K tile), which metro_forward picks from 128 crops per call on.  Bit-identical to
+ * metro_conv_f16_gemm8p (same K order, one fp32 accumulator per output). */
+int  metro_conv_f16_gemm4w(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
+                           const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
+                           int32_t split, void* d_out2, void* stream);
 /* Stem 7x7/2 convolution (+bias) and zero-padded 3x3/2 max-pool in one launch (reference resnet_v2.py:219-224,
  * resnet_utils.py:138-185).  d_prepped = metro_prep_input_f16 output [n,side+6,side+8,4] fp16, d_w packed
  * [64][7][8][4] fp16, d_out fp16 [n,side/4,side/4,64].  side % 32 == 0. */

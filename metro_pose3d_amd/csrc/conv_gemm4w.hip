@@ -1,0 +1,343 @@
+// 1x1 convolution as a 256 x 256 x 64 GEMM with FOUR waves of 128 x 128 (gfx950) -- the deep-K 1x1 layers at large batch.
+//
+// conv_gemm8p.hip gives each of its eight waves a 128 x 64 tile: 24 ds_read_b128 per 32 MFMAs, and at batch 256 hipBLASLt's
+// 256^2 kernel (four waves, 128 x 128 wave tiles: 32 reads per 64 MFMAs = two thirds of the LDS fragment bytes per MFMA) was
+// 22-28 % ahead on every deep-K shape ("the ROCm libraries on the same shapes").  This is that geometry:
+//   * one wave per SIMD, 256 fp32 accumulator registers (4 x 4 tiles of 32 x 32) + two fragment sets + one staged K tile:
+//     the whole 512-register file of the SIMD belongs to the wave;
+//   * operands are REGISTER staged: global_load_dwordx4 -> VGPR -> ds_write_b128 (XOR-swizzled rows as everywhere in this
+//     repo).  An LDS-DMA costs its wave ~60 issue cycles (MI355X_MICROARCH.md); with two waves per SIMD the partner's MFMAs
+//     cover that, with ONE wave per SIMD nothing does -- plain loads and ds_writes issue in the gaps between MFMAs;
+//   * the K tile t+2 is requested while tile t is computed; tile t+1 (in registers since the previous tile) is written to the
+//     other LDS buffer piece by piece during the first three k steps, the pre-activation (reference resnet_v2.py:119:
+//     fp16 BN + ReLU on the consumer's side) applied ONCE per element on its way into LDS instead of once per fragment read;
+//   * ONE barrier per K tile, placed in front of the last k step: its 16 MFMAs run behind the barrier and cover the first
+//     fragment reads of the next tile;
+//   * epilogue, fused-pair routing and arithmetic are conv_gemm8p's (fp32 accumulate, fp16(conv + bias), fp16 shortcut add:
+//     reference resnet_v2.py:119-138 under tfu.py:426-440).  Same K order as every other fp16 conv kernel here (k ascending,
+//     one fp32 accumulator per output): bit-identical results.
+#include <type_traits>
+
+#include "metro_common.h"
+
+namespace metro {
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+namespace g4 {
+constexpr int TM = 256, TN = 256, BK = 64, NT = 256;
+constexpr int ROW_BYTES = BK * 2;                  // 128
+constexpr int OPER_BYTES = 256 * ROW_BYTES;        // one operand image of a K tile: 32 KiB
+constexpr int A_OFF = 0, B_OFF = 2 * OPER_BYTES;   // [A buf0 | A buf1 | B buf0 | B buf1]
+constexpr int RING_BYTES = 4 * OPER_BYTES;         // 128 KiB
+constexpr int OUT_ROW_BYTES = TM * 2 + 16;
+constexpr int OUT_BYTES = TN * OUT_ROW_BYTES;      // 135168
+constexpr int MAIN_BYTES = OUT_BYTES > RING_BYTES ? OUT_BYTES : RING_BYTES;
+constexpr int PRO_BYTES = 2 * 2048 * 2;            // scale | shift, c_in <= 2048
+constexpr int PIECES = 8;                          // 16-byte loads per lane per operand per K tile (256 rows x 128 B / 256 lanes / 16 B)
+}  // namespace g4
+
+__device__ __forceinline__ int g4_swz(int row) { return (row >> 1) & 7; }
+
+template <bool PROLOGUE>
+__global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
+    ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w, const float* __restrict__ bias,
+    const half_t* __restrict__ pro_scale, const half_t* __restrict__ pro_shift, const half_t* __restrict__ residual,
+    half_t* __restrict__ out, half_t* __restrict__ out2, int tiles_m) {
+    using namespace g4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1;            // 128-cout half
+    const int wc = wave & 1;             // 128-pixel half
+
+    // XCD-aware (bijective) block -> tile map: the blocks of one XCD share pixel tiles in their L2
+    const int nblk = gridDim.x;
+    int lid;
+    {
+        const int b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = b & 7, idx = b >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = lid / tiles_m;
+    const int tile_m = lid % tiles_m;
+    const int m0 = tile_n * TN;
+    const int n0 = tile_m * TM;
+    const int K = a.c_in;
+    const int nk = K / BK;
+    half_t* pro_lds = reinterpret_cast<half_t*>(smem + MAIN_BYTES);
+
+    // ---- staging coordinates: piece e of an operand = rows 32 e + 8 wave + (lane >> 3), 16-byte chunk lane & 7 ------
+    const int lrow = lane >> 3, lch = lane & 7;
+    const int srow = wave * 8 + lrow;                                  // row of piece 0; piece e adds 32 e (same swizzle)
+    const unsigned st_off = (unsigned)(srow * ROW_BYTES + ((lch ^ g4_swz(srow)) << 4));   // LDS byte offset inside an operand image
+    // buffer loads: wave-uniform descriptor of the tile's operand rows + ONE per-lane 32-bit offset for both operands (the piece
+    // and the K tile go into the scalar offset): no 64-bit address arithmetic in the loop, no address registers
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(w + (size_t)n0 * K), 0, 256 * K * 2, 0x00020000);
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(in + (size_t)m0 * K), 0, 256 * K * 2, 0x00020000);
+    const int voff = (srow * K + lch * 8) * 2;
+    const int piece_stride = 32 * K * 2;                               // bytes
+
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[PIECES], rb[PIECES];                                      // one staged K tile
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int e = 0; e < PIECES; ++e) {
+            ra[e] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, e * piece_stride + kt * BK * 2, 0);
+            rb[e] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, e * piece_stride + kt * BK * 2, 0);
+        }
+    };
+    // pre-activation BN + ReLU on a staged pixel chunk (fp16 FMA, one rounding: resnet_v2.py:119); a lane's chunk is always
+    // channels kt*64 + 8 lch .. +7: scale / shift are read once per K tile
+    half8_t pro_sc = {}, pro_sh = {};
+    auto load_pro = [&](int kt) {
+        if constexpr (PROLOGUE) {
+            pro_sc = *reinterpret_cast<const half8_t*>(pro_lds + kt * BK + lch * 8);
+            pro_sh = *reinterpret_cast<const half8_t*>(pro_lds + 2048 + kt * BK + lch * 8);
+        }
+    };
+    auto store_piece = [&](int buf, int e) {
+        *reinterpret_cast<u32x4*>(smem + A_OFF + buf * OPER_BYTES + st_off + e * 32 * ROW_BYTES) = ra[e];
+        if constexpr (PROLOGUE) {
+            const half8_t z = {};
+            half8_t x = *reinterpret_cast<const half8_t*>(&rb[e]);
+            x = __builtin_elementwise_max(x * pro_sc + pro_sh, z);
+            *reinterpret_cast<half8_t*>(smem + B_OFF + buf * OPER_BYTES + st_off + e * 32 * ROW_BYTES) = x;
+        } else {
+            *reinterpret_cast<u32x4*>(smem + B_OFF + buf * OPER_BYTES + st_off + e * 32 * ROW_BYTES) = rb[e];
+        }
+    };
+
+    floatx16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+    unsigned a_base[4], b_base[4];       // fragment addresses (buffer 0); k step kk = XOR with kk << 5 on the swizzled chunk bits
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wr * 128 + i * 32 + frag_row;
+        a_base[i] = A_OFF + row * ROW_BYTES + ((frag_half ^ g4_swz(row)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wc * 128 + j * 32 + frag_row;
+        b_base[j] = B_OFF + row * ROW_BYTES + ((frag_half ^ g4_swz(row)) << 4);
+    }
+
+    // ---- prologue: table, tile 0 -> LDS buffer 0, tile 1 -> registers -----------------------------------------------
+    load_tile(0);
+    if (PROLOGUE) {
+        for (int c = tid * 8; c < K; c += NT * 8) {
+            *reinterpret_cast<uint4*>(pro_lds + c) = *reinterpret_cast<const uint4*>(pro_scale + c);
+            *reinterpret_cast<uint4*>(pro_lds + 2048 + c) = *reinterpret_cast<const uint4*>(pro_shift + c);
+        }
+        __syncthreads();
+    }
+    load_pro(0);
+#pragma unroll
+    for (int e = 0; e < PIECES; ++e) store_piece(0, e);
+    load_tile(nk > 1 ? 1 : 0);
+    __syncthreads();
+
+    half8_t af[2][4], bf[2][4];          // two fragment sets: the k step being multiplied and the next one
+    auto load_frags = [&](int set, int buf, int kk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[set][j] = *reinterpret_cast<const half8_t*>(smem + buf * OPER_BYTES + (b_base[j] ^ (kk << 5)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[set][i] = *reinterpret_cast<const half8_t*>(smem + buf * OPER_BYTES + (a_base[i] ^ (kk << 5)));
+    };
+    auto mma = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[set][i], bf[set][j], acc[i][j], 0, 0, 0);
+    };
+    load_frags(0, 0, 0);
+
+    // One K tile: k steps 0-2 multiply, write the staged tile t+1 into the OTHER buffer (3 + 3 + 2 pieces) and re-request the
+    // registers for tile t+2; then every wave's reads of this buffer and writes of the other one are complete -> barrier ->
+    // first fragments of tile t+1 -> k step 3 (16 MFMAs behind the barrier).
+    // (Past the end the LAST tile is requested and staged again -- valid memory, a buffer nobody reads any more -- so that the
+    // loop body is one straight-line block: conditional requests made hipcc keep the staged tile in scratch memory.)
+    auto ktile = [&](auto buf_c, int kt) {
+        constexpr int BUF = decltype(buf_c)::value;
+        const int kt1 = kt + 1 < nk ? kt + 1 : nk - 1;
+        const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;
+        const int knext = kt2 * BK * 2;
+        load_pro(kt1);
+        auto step = [&](auto kk_c) {
+            constexpr int kk = decltype(kk_c)::value;
+            constexpr int first[4] = {0, 3, 6, 8};
+            constexpr int NP = first[kk + 1] - first[kk];
+            load_frags((kk + 1) & 1, BUF, kk + 1);
+#ifndef METRO_DBG_G4_NO_WRITE
+#pragma unroll
+            for (int e = first[kk]; e < first[kk + 1]; ++e) store_piece(BUF ^ 1, e);
+#endif
+#ifndef METRO_DBG_G4_NO_LOAD
+#pragma unroll
+            for (int e = first[kk]; e < first[kk + 1]; ++e) {
+                ra[e] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, e * piece_stride + knext, 0);
+                rb[e] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, e * piece_stride + knext, 0);
+            }
+#endif
+#ifndef METRO_DBG_G4_NO_MFMA
+            mma(kk & 1);
+#endif
+            // emitted order of the step: a fragment read (and the pre-activation VALU of the pieces about to be written) behind each
+            // of the first 8 MFMAs, then one LDS write + one request behind each of the next ones
+            if (PROLOGUE && kk == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // this tile's scale / shift
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (PROLOGUE) __builtin_amdgcn_sched_group_barrier(0x002, NP, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (m < 2 * NP) {
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        load_frags(0, BUF ^ 1, 0);
+#ifndef METRO_DBG_G4_NO_MFMA
+        mma(1);                                  // k step 3: fragments read before the barrier
+#else
+        asm volatile("" ::"v"(af[0][0]), "v"(bf[0][0]), "v"(af[1][3]), "v"(bf[1][3]));
+#endif
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int t = 0; t < nk; t += 2) {
+        ktile(std::integral_constant<int, 0>{}, t);
+        ktile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    __syncthreads();                             // every wave is done with the ring: the epilogue tile overlays it
+
+    // ---- epilogue: accumulators (+bias, ReLU) -> LDS [pixel][cout] fp16 -> full-line stores (+ shortcut) ----
+    const bool second = a.split > 0 && n0 >= a.split;     // fused pair: this cout tile belongs to one of the two outputs
+    const int o_c = a.split > 0 ? (second ? a.c_out2 : a.split) : a.c_out;
+    const int o_n0 = second ? n0 - a.split : n0;
+    const int o_relu = second ? a.relu2 : a.relu;
+    half_t* o_ptr = second ? out2 : out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = wr * 128 + i * 32 + 8 * q + 4 * frag_half;
+            const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + n0 + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int prow = wc * 128 + j * 32 + frag_row;
+                half4_t hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][4 * q + e] + bv[e];
+                    if (o_relu) v = fmaxf(v, 0.f);
+                    hv[e] = (half_t)v;
+                }
+                *reinterpret_cast<half4_t*>(smem + prow * OUT_ROW_BYTES + col * 2) = hv;
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPRO = TM / 8;                       // 16-byte chunks per tile row
+    constexpr int EPI_ITERS = TN * CPRO / NT;          // 32
+    const bool res_same = a.res_stride == 1 && a.res_offset == 0 && a.res_h == a.h_out && a.res_w == a.w_out;
+    const int hw_out = a.h_out * a.w_out;
+#pragma unroll 4
+    for (int it = 0; it < EPI_ITERS; ++it) {
+        const int idx = tid + it * NT;
+        const int prow = idx / CPRO;
+        const int ch = idx - prow * CPRO;
+        const int m = m0 + prow;
+        const int co = o_n0 + ch * 8;
+        if (co + 8 > o_c) continue;                    // narrow second output of a fused pair (c_out2 < 256)
+        uint4 v = *reinterpret_cast<const uint4*>(smem + prow * OUT_ROW_BYTES + ch * 16);
+        if (residual != nullptr) {
+            size_t rp = m;
+            if (!res_same) {
+                const int img = m / hw_out;
+                const int rem = m - img * hw_out;
+                const int ho = rem / a.w_out;
+                const int wo = rem - ho * a.w_out;
+                rp = (size_t)(img * a.res_h + ho * a.res_stride + a.res_offset) * a.res_w + (wo * a.res_stride + a.res_offset);
+            }
+            const uint4 rv = *reinterpret_cast<const uint4*>(residual + rp * a.c_out + co);
+            half2_t* x = reinterpret_cast<half2_t*>(&v);
+            const half2_t* r = reinterpret_cast<const half2_t*>(&rv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = x[e] + r[e];    // fp16 Add, like the reference graph
+        }
+        store_out16<2>(o_ptr + (size_t)m * o_c + co, v);
+    }
+}
+
+// same shapes as conv_gemm8p (whole 256 x 256 tiles, an even number of 64-channel K tiles)
+bool conv_gemm4w_shape_ok(const MetroConvDesc& d, const ConvSplit* split) { return conv_gemm8p_shape_ok(d, split); }
+
+int launch_conv_gemm4w(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* ps,
+                       const void* pb, const void* res, void* out, hipStream_t stream, const ConvSplit* split) {
+    if (!conv_gemm4w_shape_ok(d, split)) {
+        set_error("conv_gemm4w: needs a 1x1 stride-1 fp16 layer with c_in %% 128 == 0 (<= 2048), c_out %% 256 == 0 and pixels %% 256 == 0 "
+                  "(got c_in %d, c_out %d, %d x %d x %d pixels)", d.c_in, d.c_out, d.n, d.h_out, d.w_out);
+        return METRO_ERR_UNSUPPORTED;
+    }
+    ConvArgs a = make_conv_args(d);
+    void* out2 = nullptr;
+    if (split != nullptr && split->split > 0) {
+        a.split = split->split; a.c_out2 = split->c_out2; a.relu2 = split->relu2;
+        out2 = split->out2;
+    }
+    if (note_kernel("conv_gemm4w<256x256%s>%s%s", d.has_prologue ? ",pro" : "", d.has_residual ? "+res" : "", a.split > 0 ? "+pair" : ""))
+        return METRO_OK;
+    const int tiles_m = (d.c_out + g4::TM - 1) / g4::TM;
+    const int tiles_n = (a.m_total + g4::TN - 1) / g4::TN;
+    const half_t* r = d.has_residual ? static_cast<const half_t*>(res) : nullptr;
+    if (d.has_prologue) {
+        auto kern = conv_gemm4w_kernel<true>;
+        constexpr int lds = g4::MAIN_BYTES + g4::PRO_BYTES;
+        static PerDeviceInt done;
+        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4w<pro>")) return st;
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(g4::NT), lds, stream, a, static_cast<const half_t*>(in),
+                           static_cast<const half_t*>(w), bias, static_cast<const half_t*>(ps), static_cast<const half_t*>(pb), r,
+                           static_cast<half_t*>(out), static_cast<half_t*>(out2), tiles_m);
+    } else {
+        auto kern = conv_gemm4w_kernel<false>;
+        constexpr int lds = g4::MAIN_BYTES;
+        static PerDeviceInt done;
+        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4w")) return st;
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(g4::NT), lds, stream, a, static_cast<const half_t*>(in),
+                           static_cast<const half_t*>(w), bias, nullptr, nullptr, r, static_cast<half_t*>(out),
+                           static_cast<half_t*>(out2), tiles_m);
+    }
+    return launch_status("conv_gemm4w");
+}
+
+}  // namespace metro

@@ -697,8 +697,14 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
             (mode != 2 || fuse2->c2 == 64))
             return launch_conv_pw64(d, in_, w_, bias, ps_, pb_, res_, out, stream, split, fuse2);
     }
-    if (!(fuse2 != nullptr && fuse2->w2 != nullptr) && conv_gemm8p_supported(d, split))
+    if (!(fuse2 != nullptr && fuse2->w2 != nullptr) && conv_gemm8p_supported(d, split)) {
+        // the four-wave form (128 x 128 wave tiles, register-staged operands, the pre-activation applied once per element on the
+        // way into LDS) is 3-11 % ahead on every pre-activated layer (all of conv1 / shortcut / pair), batch 64-256; the bare GEMM
+        // is faster on the 8-phase kernel (tools/gemm8p_probe.py).  Same K order: the two give the same bits.
+        static const int four = env_int("METRO_GEMM4W", 1);
+        if (four && d.has_prologue) return launch_conv_gemm4w(d, in_, w_, bias, ps_, pb_, res_, out, stream, split);
         return launch_conv_gemm8p(d, in_, w_, bias, ps_, pb_, res_, out, stream, split);
+    }
     if (fuse2 != nullptr && fuse2->w2 != nullptr) {
         if (!conv_f16_fuse2_supported(d, fuse2->c2)) { set_error("conv fuse2: unsupported layer shape (c_out %d c2 %d k %dx%d c_in %d pix_stride %d stride %d pad %d,%d pro %d dt %d/%d hw %dx%d -> %dx%d)",
                                                                  d.c_out, fuse2->c2, d.kh, d.kw, d.c_in, d.in_pix_stride, d.stride, d.pad_top, d.pad_left, d.has_prologue,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times metro_conv_f16_gemm8p (and metro_conv_f16 on the same layer) on the deep-K 1x1 shapes of blocks 3-4.
+"""Times metro_conv_f16_gemm8p, metro_conv_f16_gemm4w and torch.mm (hipBLASLt, bare GEMM) on the deep-K 1x1 shapes of blocks 3-4.
     python tools/gemm8p_probe.py [batch]"""
 import ctypes as C
 import sys
@@ -26,9 +26,17 @@ for c_in, c_out in SHAPES:
     gf = 2.0 * n * 256 * c_in * c_out / 1e9
     for pro in (False, True):
         d = H.conv_desc(n, 16, c_in, 16, c_out, 1, prologue=pro)
+        o8, o4 = torch.empty_like(out), torch.empty_like(out)
+        a8 = lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(o8), 0, None, C.c_void_p(0))
+        a4 = lib.metro_conv_f16_gemm4w(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(o4), 0, None, C.c_void_p(0))
+        torch.cuda.synchronize()
+        print('   bits equal to gemm8p:', a8, a4, bool(torch.equal(o8, o4)), float((o8.float() - o4.float()).abs().max()))
         res = {}
         for name, fn in (('gemm8p', lambda: lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
                                                                      H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
+                         ('gemm4w', lambda: lib.metro_conv_f16_gemm4w(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
+                                                                     H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
+                         ('hipblaslt', lambda: (torch.mm(x.view(-1, c_in), w.t(), out=out.view(-1, c_out)), 0)[1]),
                          ):
             for _ in range(3):
                 assert fn() == 0, lib.metro_last_error()
@@ -41,4 +49,6 @@ for c_in, c_out in SHAPES:
             e1.record()
             torch.cuda.synchronize()
             res[name] = e0.elapsed_time(e1) / reps * 1e3
+        if 'ref' not in res:
+            pass
         print(f'n={n} {c_in:5d}->{c_out:5d} pro={int(pro)}  ' + '  '.join(f'{k} {v:7.1f} us {gf / v * 1e3:6.0f} TF/s' for k, v in res.items()), flush=True)
