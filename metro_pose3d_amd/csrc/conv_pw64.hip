@@ -22,6 +22,12 @@
 //                  sc = fp16(Wsc . fp16(relu(x * scale + shift)) + bias_sc) (resnet_v2.py:119,122-125) added to
 //                  fp16(conv3 + bias) in registers -- 128 instead of 512 shortcut bytes per pixel, and the launch that
 //                  wrote the shortcut tensor (512 more) is gone.
+//       CB = 512   (K = 128, block2) ALL 512 output channels of a 32-pixel tile in one block (wave tile 64 couts x 32 pixels,
+//                  W3 = 64 VGPRs per lane) so that MODE2 = 2 works there too: the next unit's conv1 (512 -> 128) needs every
+//                  channel of a pixel.  Its weights W1' [128][512] live in REGISTERS as well -- wave w owns output rows
+//                  16 w .. 16 w + 15 and runs 2 x 16 v_mfma_f32_16x16x32_f16 over the whole K = 512 from the LDS tile: no
+//                  split K, no cross-wave reduction.  block2's conv1 launches (24 us each at batch 64, re-reading the 67 MB
+//                  residual stream the conv3 launch just wrote) are gone.
 // Arithmetic is that of the tiled kernel: fp32 accumulate, fp16(conv + bias), then the fp16 shortcut add.
 #include <cstdlib>
 
@@ -46,7 +52,7 @@ struct Pw64Args {
     const half_t* pro_shift;
     const half_t* residual;    // [m_total][256]  (RES)
     half_t* out;               // [m_total][256]
-    const half_t* w2;          // MODE2 = 1: [64][64];  MODE2 = 2: [64][256]
+    const half_t* w2;          // MODE2 = 1: [64][64];  MODE2 = 2: [64][256] (CB = 256) / [128][512] (CB = 512)
     const float* bias2;        // [64]
     const half_t* scale2;      // [256]  (MODE2 = 2)
     const half_t* shift2;
@@ -55,7 +61,7 @@ struct Pw64Args {
     const half_t* w_sc;        // PSC: [256][64]
     const float* bias_sc;      // PSC: [256]
     int m_total, n_tiles;
-    int c_out;                 // 256 * (number of 256-channel halves); block b serves half b % halves
+    int c_out;                 // CB * (number of CB-channel slabs); block b serves slab b % halves
     // sub-sampled shortcut (units with stride 2, reference resnet_v2.py:113-118: max_pool2d 1x1 stride 2 of the
     // unit input): output pixel (ho, wo) adds input pixel (res_off + 2*ho, res_off + 2*wo) of a res_h x res_w map
     int res_stride, res_off, res_h, res_w, h_out, w_out;
@@ -63,31 +69,39 @@ struct Pw64Args {
 
 namespace pw {
 constexpr int NW = 8, NT = 512;
-constexpr int OUT_ROW = 256 * 2 + 16;          // padded rows of the [pixel][cout] tile
-// WM = waves along the 256 output channels: 4 -> wave tile 64 couts x 32 pixels, 64-pixel tiles (weights K/2
-// VGPRs per lane: K <= 128); 8 -> wave tile 32 couts x 32 pixels, 32-pixel tiles (K/4 VGPRs: K <= 512)
-template <int K, int WM>
+// WM = waves along the output channels of a block, CB = output channels per block:
+//   WM 4, CB 256: wave tile 64 couts x 32 pixels, 64-pixel tiles (weights K/2 VGPRs per lane: K <= 128)
+//   WM 8, CB 256: wave tile 32 couts x 32 pixels, 32-pixel tiles (K/4 VGPRs: K <= 512)
+//   WM 8, CB 512: wave tile 64 couts x 32 pixels, 32-pixel tiles (K/2 VGPRs: K = 128), every channel of a pixel in one block
+template <int K, int WM, int CB = 256>
 struct Lay {
     static constexpr int WN = NW / WM;
-    static constexpr int NI = 8 / WM;               // 32-row MFMA tiles per wave
+    static constexpr int NI = CB / 32 / WM;         // 32-row MFMA tiles per wave
     static constexpr int TN = 32 * WN;              // pixels per tile
     static constexpr int KS = K / 64;               // input tile = KS swizzled slices of TN rows x 64 fp16
     static constexpr int SL_BYTES = TN * 128;
     static constexpr int X_BYTES = KS * SL_BYTES;
     static constexpr int XI = X_BYTES / 1024 / NW;  // input DMA instructions per wave per tile
-    static constexpr int RI = TN / 16;              // row-wise iterations = shortcut DMA instructions = stores per wave
+    static constexpr int CPR = CB / 8;              // 16-byte chunks per output row
+    static constexpr int RI = TN * CPR / NT;        // row-wise iterations = shortcut DMA instructions = stores per wave
+    static constexpr int OUT_ROW = CB * 2 + 16;     // padded rows of the [pixel][cout] tile
     static constexpr int OUT_BYTES = TN * OUT_ROW;
-    static constexpr int RES_BYTES = TN * 512;
-    static constexpr int PAR_BYTES = 1024 + 256 + 4 * K + 1024;   // bias[256] f32 | bias2[64] f32 | pro scale[K] | pro shift[K] fp16 | bias_sc[256] f32 (PSC)
+    static constexpr int RES_BYTES = TN * CB * 2;
+    static constexpr int C2 = CB == 512 ? 128 : 64; // channels of a second output
+    // bias[CB] f32 | bias2[128] f32 | pro scale[K] | pro shift[K] fp16 | bias_sc[256] f32 (PSC)
+    static constexpr int BIAS2_OFF = CB * 4, PRO_OFF = BIAS2_OFF + 512, BSC_OFF = PRO_OFF + 4 * K;
+    static constexpr int PAR_BYTES = BSC_OFF + 1024;
     static constexpr int X_OFF = 0;                 // 2 buffers
     static constexpr int OUT_OFF = X_OFF + 2 * X_BYTES;
     static constexpr int PAR_OFF = OUT_OFF + OUT_BYTES;
     static constexpr int RES_OFF = PAR_OFF + PAR_BYTES;   // 2 buffers (RES)
     static_assert(X_BYTES % (1024 * NW) == 0, "input tile must split evenly over the waves");
+    static_assert(NI >= 1 && RI >= 1 && (TN * CPR) % NT == 0, "tile / thread mismatch");
 };
-template <int K, int WM, bool RES, int MODE2, bool PSC = false>
+template <int K, int WM, bool RES, int MODE2, bool PSC = false, int CB = 256>
 constexpr int lds_bytes() {
-    return Lay<K, WM>::RES_OFF + (RES ? 2 * Lay<K, WM>::RES_BYTES : PSC ? 2 * Lay<K, WM>::X_BYTES : 0) + (MODE2 == 2 ? 64 * 256 * 2 : 0);
+    return Lay<K, WM, CB>::RES_OFF + (RES ? 2 * Lay<K, WM, CB>::RES_BYTES : PSC ? 2 * Lay<K, WM, CB>::X_BYTES : 0) +
+           (MODE2 == 2 && CB == 256 ? 64 * 256 * 2 : 0);
 }
 }  // namespace pw
 
@@ -109,16 +123,17 @@ __device__ __forceinline__ void pw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false, bool PSC = false>
+template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false, bool PSC = false, int CB = 256>
 __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     using namespace pw;
-    using L = Lay<K, WM>;
+    using L = Lay<K, WM, CB>;
     static_assert((WM == 4 && K <= 128) || (WM == 8 && K <= 512), "weights must fit the register file as MFMA fragments");
-    static_assert(MODE2 == 0 || (K == 64 && WM == 4), "second outputs are block1 shapes");
+    static_assert(CB == 256 || (CB == 512 && K == 128 && WM == 8 && RES && !PRO && !RSUB), "512-channel blocks: conv3 of block2");
+    static_assert(MODE2 == 0 || (K == 64 && WM == 4) || (MODE2 == 2 && CB == 512), "second outputs: block1 shapes, or conv3 + next conv1 of block2");
     static_assert(!PSC || (MODE2 == 2 && !PRO && !RES), "in-launch projection shortcut: conv3 + next conv1 of block1/unit_1");
     constexpr int KK = K / 16, WN = L::WN, NI = L::NI, TN = L::TN, XI = L::XI, RI = L::RI;
     constexpr int X_BYTES = L::X_BYTES, X_OFF = L::X_OFF, OUT_OFF = L::OUT_OFF, PAR_OFF = L::PAR_OFF, RES_OFF = L::RES_OFF,
-                  RES_BYTES = L::RES_BYTES, SL_BYTES = L::SL_BYTES;
+                  RES_BYTES = L::RES_BYTES, SL_BYTES = L::SL_BYTES, OUT_ROW = L::OUT_ROW, CPR = L::CPR, C2 = L::C2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void_t;
     const unsigned smem_base = (unsigned)(size_t)(lds_void_t*)smem;
@@ -130,10 +145,10 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;           // wave tile: couts wm*32*NI.., pixels wn*32..+32
     const int frag_row = lane & 31, frag_half = lane >> 5;
-    // 256-channel slabs of wider outputs go to different blocks (the weights are register-resident).  Blocks are
+    // CB-channel slabs of wider outputs go to different blocks (the weights are register-resident).  Blocks are
     // dealt round-robin to the 8 XCDs (one L2 each): the `halves` blocks that share an input tile are placed on the
     // SAME XCD (PMC: with consecutive block ids block4's conv3 fetched its input 8 times, 203 MB instead of 84 MB).
-    const int halves = a.c_out >> 8;
+    const int halves = a.c_out / CB;
     const int G = gridDim.x / halves;                       // tile streams
     int half, t;
     if ((gridDim.x & 7) == 0 && ((gridDim.x >> 3) % halves) == 0) {
@@ -145,10 +160,10 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         t = blockIdx.x / halves;
     }
     if (t >= a.n_tiles) return;
-    a.w += (size_t)half * 256 * K;
-    a.bias += half * 256;
-    a.out += half * 256;
-    if (RES) a.residual += half * 256;
+    a.w += (size_t)half * CB * K;
+    a.bias += half * CB;
+    a.out += half * CB;
+    if (RES) a.residual += half * CB;
     const int ldo = a.c_out;
     const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page_pw);
 
@@ -176,17 +191,25 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         }
     }
     float* bias_l = reinterpret_cast<float*>(smem + PAR_OFF);
-    float* bias2_l = bias_l + 256;
-    half_t* pro_l = reinterpret_cast<half_t*>(smem + PAR_OFF + 1280);
-    if (tid < 256) bias_l[tid] = a.bias[tid];
-    if (MODE2 != 0 && tid < 64) bias2_l[tid] = a.bias2[tid];
+    float* bias2_l = reinterpret_cast<float*>(smem + PAR_OFF + L::BIAS2_OFF);
+    half_t* pro_l = reinterpret_cast<half_t*>(smem + PAR_OFF + L::PRO_OFF);
+    if (tid < CB) bias_l[tid] = a.bias[tid];
+    if (MODE2 != 0 && tid < C2) bias2_l[tid] = a.bias2[tid];
     if ((PRO || PSC) && tid < K) { pro_l[tid] = a.pro_scale[tid]; pro_l[K + tid] = a.pro_shift[tid]; }
-    float* bias_sc_l = reinterpret_cast<float*>(smem + PAR_OFF + 1280 + 4 * K);
+    float* bias_sc_l = reinterpret_cast<float*>(smem + PAR_OFF + L::BSC_OFF);
     if (PSC && tid < 256) bias_sc_l[tid] = a.bias_sc[tid];
     // row-wise pass: this thread always owns 16-byte chunk `ch` of a row
-    const int ch = tid & 31;
+    const int ch = tid & (CPR - 1);
     half8_t sc2 = {}, sh2 = {};
-    if constexpr (MODE2 == 2) {
+    half8_t w2r[CB == 512 ? 16 : 1];                         // CB = 512: W1' rows 16 wave .. +15, all 512 k, as 16x16x32 A fragments
+    if constexpr (MODE2 == 2 && CB == 512) {
+        sc2 = *reinterpret_cast<const half8_t*>(a.scale2 + ch * 8);
+        sh2 = *reinterpret_cast<const half8_t*>(a.shift2 + ch * 8);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            w2r[ks] = *reinterpret_cast<const half8_t*>(a.w2 + (size_t)(wave * 16 + (lane & 15)) * 512 + ks * 32 + (lane >> 4) * 8);
+    }
+    if constexpr (MODE2 == 2 && CB == 256) {
         sc2 = *reinterpret_cast<const half8_t*>(a.scale2 + ch * 8);
         sh2 = *reinterpret_cast<const half8_t*>(a.shift2 + ch * 8);
         // W2 [64][256] as 4 swizzled images of 64 rows x 64 k (one per 64-channel slice of K)
@@ -221,12 +244,12 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
             }
         }
         if constexpr (RES) {
-            // shortcut rows: chunk c = it*512 + tid (row c/32, 16-byte column c%32) lands at c*16, i.e. every
+            // shortcut rows: chunk c = it*512 + tid (row c / CPR, 16-byte column c % CPR) lands at c*16, i.e. every
             // wave later reads back exactly the bytes it requested
 #pragma unroll
             for (int it = 0; it < RI; ++it) {
                 const int c = it * NT + tid;
-                const int m = m0 + (c >> 5);
+                const int m = m0 + c / CPR;
                 size_t rrow = m;
                 if constexpr (RSUB) {
                     const int hw = a.h_out * a.w_out;
@@ -234,7 +257,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
                     const int ho = rem / a.w_out, wo = rem - ho * a.w_out;
                     rrow = ((size_t)img * a.res_h + a.res_off + a.res_stride * ho) * a.res_w + a.res_off + a.res_stride * wo;
                 }
-                const half_t* rs = m < a.m_total ? a.residual + rrow * ldo + (c & 31) * 8 : zero;
+                const half_t* rs = m < a.m_total ? a.residual + rrow * ldo + (c & (CPR - 1)) * 8 : zero;
                 pw_dma16(rs, __builtin_amdgcn_readfirstlane(smem_base + RES_OFF + buf * RES_BYTES + it * 8192 + wave * 1024));
             }
         }
@@ -242,14 +265,16 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
 
     issue_tile(t, 0);
     // stores of one tile per wave (all younger than the next tile's loads): RI row-wise (+4 second-output)
-    const bool two = MODE2 != 0 && wave < 4;
+    // second-output stores: CB 256: four 8-byte stores by waves 0-3; CB 512: two by every wave
+    constexpr int S2 = CB == 512 ? 2 : 4;
+    const bool two = MODE2 != 0 && (CB == 512 || wave < 4);
     bool prev_full = false;
     for (int it = 0;; ++it, t += G) {
         const int buf = it & 1;
         const int m0 = t * TN;
         // ---- the tile's loads have landed (for this wave), then for every wave -----------------
         if (it == 0 || !prev_full) pw_wait_vm<0>();
-        else if (two) pw_wait_vm<RI + 4>();
+        else if (two) pw_wait_vm<RI + S2>();
         else pw_wait_vm<RI>();
         pw_barrier();
         if (t + G < a.n_tiles) issue_tile(t + G, buf ^ 1);
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
 #pragma unroll
         for (int r = 0; r < RI; ++r) {
             const int idx = tid + r * NT;
-            const int prow = idx >> 5;
+            const int prow = idx / CPR;
             const int m = m0 + prow;
             uint4 v = *reinterpret_cast<const uint4*>(ol + prow * OUT_ROW + ch * 16);
             if constexpr (RES) {
@@ -355,7 +380,33 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
                 *reinterpret_cast<half8_t*>(ol + prow * OUT_ROW + ch * 16) = p;
             }
         }
-        if constexpr (MODE2 == 2) {
+        if constexpr (MODE2 == 2 && CB == 512) {
+            pw_barrier();
+            // ---- GEMM 2: [128 x 512] x [512 x 32 pixels] from the tile: wave w = output rows 16 w .. 16 w + 15, two 16-pixel tiles,
+            //      16 k steps of 32 (v_mfma_f32_16x16x32_f16: A[i][k] lane (i = lane & 15, k group = lane >> 4), B likewise by pixel)
+            floatx4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+            const char* bl = ol + (lane & 15) * OUT_ROW + (lane >> 4) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const half8_t b0 = *reinterpret_cast<const half8_t*>(bl + ks * 64);
+                const half8_t b1 = *reinterpret_cast<const half8_t*>(bl + 16 * OUT_ROW + ks * 64);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2r[ks], b0, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2r[ks], b1, d1, 0, 0, 0);
+            }
+            // D[i][j]: lane (j = lane & 15 -> pixel, i group = lane >> 4 -> rows 4 (lane >> 4) .. + 3)
+            const int co = wave * 16 + (lane >> 4) * 4;
+            const floatx4 bv = *reinterpret_cast<const floatx4*>(bias2_l + co);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = m0 + j * 16 + (lane & 15);
+                const floatx4 dv = j == 0 ? d0 : d1;
+                half4_t hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (half_t)fmaxf(dv[e] + bv[e], 0.f);
+                if (m < a.m_total) *reinterpret_cast<half4_t*>(a.out2 + (size_t)m * C2 + co) = hv;
+            }
+        }
+        if constexpr (MODE2 == 2 && CB == 256) {
             pw_barrier();
             // ---- GEMM 2: [64 x 256] x [256 x 64 pixels] from the tile (waves 0..3, one 32x32 tile each)
             if (wave < 4) {
@@ -407,7 +458,10 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
     if (d.has_residual && !res_plain && !(mode == 0 && res_sub && d.c_in <= 128)) return false;
     // built combinations: prologue without shortcut (projection shortcut, pair) / shortcut without prologue (conv3)
     if (mode == 1) return d.c_in == 64 && d.c_out == 320 && d.has_prologue && !d.has_residual;
-    if (mode == 2) return d.c_in == 64 && d.c_out == 256 && !d.has_prologue && d.has_residual;
+    if (mode == 2) {
+        static const int next128 = pw_env_int("METRO_PW_NEXT128", 1);
+        return ((d.c_in == 64 && d.c_out == 256) || (next128 && d.c_in == 128 && d.c_out == 512 && res_plain)) && !d.has_prologue && d.has_residual;
+    }
     if (mode == 3) return d.c_in == 64 && d.c_out == 256 && !d.has_prologue && !d.has_residual;    // + in-launch projection shortcut
     if (d.c_in == 64 && d.c_out == 256) return (d.has_prologue != 0) != (d.has_residual != 0);
     // conv3 (+ shortcut) of blocks 2-4: c_out = 4 * c_in in 256-channel slabs (METRO_PW_MAXK caps c_in for A/B runs)
@@ -416,20 +470,20 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
            !d.has_prologue && d.has_residual;
 }
 
-template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false, bool PSC = false>
+template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false, bool PSC = false, int CB = 256>
 static int launch_pw(Pw64Args a, hipStream_t stream) {
-    if (note_kernel("conv_pw64<k%d,wm%d%s%s%s%s%s>", K, WM, PRO ? ",pro" : "", RES ? ",res" : "",
+    if (note_kernel("conv_pw64<k%d,wm%d%s%s%s%s%s%s>", K, WM, CB == 512 ? ",cb512" : "", PRO ? ",pro" : "", RES ? ",res" : "",
                     MODE2 == 1 ? ",pair" : MODE2 == 2 ? ",next" : "", RSUB ? ",ressub" : "", PSC ? ",projsc" : ""))
         return METRO_OK;
-    auto kern = conv_pw64_kernel<K, WM, PRO, RES, MODE2, RSUB, PSC>;
-    constexpr int lds = pw::lds_bytes<K, WM, RES, MODE2, PSC>();
-    a.n_tiles = (a.m_total + pw::Lay<K, WM>::TN - 1) / pw::Lay<K, WM>::TN;
+    auto kern = conv_pw64_kernel<K, WM, PRO, RES, MODE2, RSUB, PSC, CB>;
+    constexpr int lds = pw::lds_bytes<K, WM, RES, MODE2, PSC, CB>();
+    a.n_tiles = (a.m_total + pw::Lay<K, WM, CB>::TN - 1) / pw::Lay<K, WM, CB>::TN;
     static PerDeviceInt cap;
     int grid_cap = 0;
     if (const int st = ensure_dyn_lds_and_grid_cap(reinterpret_cast<const void*>(kern), pw::NT, lds, cap, "conv_pw64",
                                                    pw_env_int("METRO_PW64_BPC", 0) /* blocks per CU, 0 = what fits */, &grid_cap))
         return st;
-    const int halves = a.c_out / 256;
+    const int halves = a.c_out / CB;
     int grid = a.n_tiles * halves < grid_cap ? a.n_tiles * halves : grid_cap;
     grid -= grid % halves;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(pw::NT), lds, stream, a);
@@ -443,7 +497,7 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
     const int mode = (f2 != nullptr && f2->w2 != nullptr) ? (proj ? 3 : 2) : (split != nullptr && split->split > 0) ? 1 : 0;
     if (proj && mode != 3) { set_error("conv_pw64: the in-launch projection shortcut exists for conv3 + next conv1 only"); return METRO_ERR_INVALID_ARG; }
     if (!conv_pw64_supported(d, mode) || (mode == 1 && !(split->split == 256 && split->c_out2 == 64 && split->relu2 == 1)) ||
-        (mode >= 2 && f2->c2 != 64)) {
+        (mode >= 2 && f2->c2 != (d.c_in == 128 ? 128 : 64))) {
         set_error("conv_pw64: unsupported layer");
         return METRO_ERR_INVALID_ARG;
     }
@@ -476,6 +530,7 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
             a.pro_scale = static_cast<const half_t*>(psc->pro_scale); a.pro_shift = static_cast<const half_t*>(psc->pro_shift);
             return launch_pw<64, 4, false, false, 2, false, true>(a, stream);
         }
+        if (d.c_in == 128) return launch_pw<128, 8, false, true, 2, false, false, 512>(a, stream);
         return launch_pw<64, 4, false, true, 2>(a, stream);
     }
     if (d.c_in == 512) return launch_pw<512, 8, false, true, 0>(a, stream);

@@ -518,7 +518,9 @@ int build_plan(MetroPlan* p) {
             if (fast && u < n_units[b] && s == 1) {
                 MetroConvDesc probe = p->layers.back().cd;
                 probe.n = 1;
-                if (conv_f16_fuse2_supported(probe, cb) || unit_fused) {
+                // block2 (128 -> 512 on 32-wide maps): the persistent kernel with all 512 channels of a pixel tile in one block
+                const bool pw_next = probe.c_in == 128 && cb == 128 && conv_pw64_supported(probe, 2);
+                if (conv_f16_fuse2_supported(probe, cb) || unit_fused || pw_next) {
                     const std::string un2 = "block" + std::to_string(b + 1) + "/unit_" + std::to_string(u + 1);
                     B.fuse_next_conv1(un2, un2 + "/bottleneck_v2", side_out, cout, cb);
                     conv1_done = true;
@@ -919,8 +921,8 @@ int metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d_
     METRO_CHECK_ARG(d_in && d_w && d_bias && d_out && d_w2 && d_bias2 && d_scale2 && d_shift2 && d_out2,
                     "conv_f16_next: NULL tensor pointer");
     METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f16_next: residual tensor missing");
-    METRO_CHECK_ARG(conv_f16_fuse2_supported(*d, c2) || conv_pw64_supported(*d, 2),
-                    "conv_f16_next: built for 1x1 stride-1 64 -> 256 with c2 = 64 (block1), fp16");
+    METRO_CHECK_ARG(conv_f16_fuse2_supported(*d, c2) || (conv_pw64_supported(*d, 2) && c2 == (d->c_in == 128 ? 128 : 64)),
+                    "conv_f16_next: built for 1x1 stride-1 64 -> 256 with c2 = 64 (block1) and 128 -> 512 with c2 = 128 (block2), fp16");
     ConvFuse2 f2;
     f2.w2 = d_w2; f2.bias2 = d_bias2; f2.scale2 = d_scale2; f2.shift2 = d_shift2; f2.out2 = d_out2; f2.c2 = c2;
     return launch_conv_f16_dma(*d, d_in, d_w, d_bias, nullptr, nullptr, d_residual, d_out,

@@ -183,13 +183,17 @@ def test_conv_f16_pair(lib, cuda, shape):
     assert np.abs(got2 - np.maximum(ref[..., c_sc:], 0)).max() <= tol
 
 
-@pytest.mark.parametrize('shape', [(3, 7), (2, 8), (12, 64)], ids=['ragged', 'small', 'many_tiles'])
+@pytest.mark.parametrize('shape', [(3, 7), (2, 8), (12, 64), (3, 7, 128), (2, 8, 128), (25, 32, 128)],
+                         ids=['ragged', 'small', 'many_tiles', 'block2_ragged', 'block2_small', 'block2_many_tiles'])
 def test_conv_f16_next(lib, cuda, shape):
     """conv3 + shortcut of unit u and conv1 of unit u+1 in one launch (reference resnet_v2.py:134-138 then
     :119,127-128): first output against the fp64 reference, second output against a restatement on the fp16
-    first output the kernel itself stored (tight)."""
-    n, h = shape
-    c_in, c_out, c2 = 64, 256, 64
+    first output the kernel itself stored (tight).  block1 shapes (64 -> 256, next conv1 256 -> 64) and block2 shapes
+    (128 -> 512, next conv1 512 -> 128: all 512 channels of a 32-pixel tile in one block, W1' in registers,
+    v_mfma_f32_16x16x32_f16 from the LDS tile)."""
+    n, h = shape[:2]
+    c_in = shape[2] if len(shape) > 2 else 64
+    c_out, c2 = 4 * c_in, c_in
     rng = np.random.default_rng(zlib.crc32(repr(shape).encode()) + 1)
     x, w, b = _mk(rng, n, h, c_in, c_out, 1)
     res = rng.standard_normal((n, h, h, c_out)).astype(np.float16)
