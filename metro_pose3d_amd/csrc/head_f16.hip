@@ -238,6 +238,205 @@ __global__ __launch_bounds__(hd::NT) void head_f16_kernel(HeadArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same head with 256-PIXEL tiles, for heads with at least one such tile per CU (RN50-s4 at 16 crops, the stride-16 nets
+// from 256 crops on).  A 64-pixel tile re-streams the head's 557 KB of weights for 0.14 GFLOP (44 FLOP/B through the L2 -> LDS
+// path: the C5 head took 142 us where its HBM bytes need 13); with 256 pixels the weights stream once per FOUR times the
+// pixels.  Geometry: 8 waves = 8 x 32 pixels, every wave all <= 160 channels (5 accumulator tiles), the WHOLE K per wave:
+// no K-quarters to add up.  Five 26 KiB stages (160 weight rows + 256 pixel rows of 32 channels: four K steps = 104 KiB in
+// flight per CU -- with two 52 KiB stages every step paid a whole memory latency: 112 us); then the block walks its
+// four 64-pixel chunks: the two owning waves put their fp32 logits (+ bias) into the LDS tile, all eight waves take the
+// per-joint softmax statistics exactly as above -- ONE record per (image, 64-pixel slab, joint), the same partials layout
+// and slab count as the 64-pixel kernel, so softargmax_finalize does not care which one ran.
+namespace hd2 {
+constexpr int TM = 160, MT = 5, TN = 256, BK = 32, NW = 8, NT = 512, STAGES = 5;
+constexpr int ROW_BYTES = BK * 2;                      // 64: four 16-byte chunks, swizzled by (row >> 2) & 3
+constexpr int STAGE_BYTES = (TM + TN) * ROW_BYTES;     // 26 KiB
+constexpr int RING_BYTES = STAGES * STAGE_BYTES;       // 130 KiB: four K steps (104 KiB) in flight per CU
+constexpr int LROW = 161;
+constexpr int LOGITS_BYTES = 64 * LROW * 4;            // fp32 logits of one 64-pixel chunk: overlays the ring after the K loop
+constexpr int PRO_OFF = RING_BYTES;
+constexpr int LDS_BYTES = PRO_OFF + 2 * 2048 * 2;
+constexpr int GA = TM / 16, GB = TN / 16;              // DMA instructions (16 rows each) per K step: 10 weight + 16 pixel groups
+constexpr int WTILE_BYTES = 4 * 32 * LROW * 4;           // four wave-private [32][161] fp32 tiles per round
+static_assert(LDS_BYTES <= 160 * 1024 && LOGITS_BYTES <= RING_BYTES && WTILE_BYTES <= RING_BYTES && GA <= 2 * NW && GB == 2 * NW, "LDS / loader split");
+}  // namespace hd2
+
+__device__ __forceinline__ int hd2_swz(int row) { return (row >> 2) & 3; }
+
+__global__ __launch_bounds__(hd2::NT) void head_f16_kernel256(HeadArgs a) {
+    using namespace hd2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x, img = blockIdx.y;
+    const int m0 = img * a.pixels + tile * TN;
+    const int K = a.K, nk = K / BK;
+    const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page_head);
+    const unsigned smem_base = (unsigned)(size_t)(hd_lds_void_t*)smem;
+    half_t* pro_lds = reinterpret_cast<half_t*>(smem + PRO_OFF);
+
+    // ---- DMA sources per K step (one instruction = 16 rows x 64 B): weight groups g = wave, wave + 8 (< 10), pixel groups
+    //      wave, wave + 8: waves 0-1 issue four per step, waves 2-7 three
+    const int lrow = lane >> 2, lch = lane & 3;
+    const int na = wave < GA - NW ? 2 : 1;
+    const half_t* srcw[2];
+    const half_t* srcx[2];
+    int incw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave + NW * i) * 16 + lrow;
+        const bool ok = row < a.C;
+        srcw[i] = ok ? a.w + (size_t)row * K + ((lch ^ hd2_swz(row)) * 8) : zero;
+        incw[i] = ok ? BK : 0;
+        const int prow = (wave + NW * i) * 16 + lrow;
+        srcx[i] = a.x + (size_t)(m0 + prow) * K + ((lch ^ hd2_swz(prow)) * 8);
+    }
+    auto issue_step = [&](int slot) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(smem_base + slot * STAGE_BYTES);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i < na) {
+#ifndef METRO_DBG_HD2_NO_W
+                hd_dma16(srcw[i], base + (wave + NW * i) * 16 * ROW_BYTES);
+#endif
+                srcw[i] += incw[i];
+            }
+#ifndef METRO_DBG_HD2_NO_X
+            hd_dma16(srcx[i], base + TM * ROW_BYTES + (wave + NW * i) * 16 * ROW_BYTES);
+#endif
+            srcx[i] += BK;
+        }
+    };
+
+    floatx16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < nk) issue_step(st);
+    for (int c = tid * 8; c < K; c += NT * 8) {
+        *reinterpret_cast<uint4*>(pro_lds + c) = *reinterpret_cast<const uint4*>(a.pro_scale + c);
+        *reinterpret_cast<uint4*>(pro_lds + 2048 + c) = *reinterpret_cast<const uint4*>(a.pro_shift + c);
+    }
+    __syncthreads();      // table visible (drains the DMAs issued so far as well: once per block)
+
+    const int brow = wave * 32 + frag_row;
+    const int b_off = TM * ROW_BYTES + brow * ROW_BYTES;
+    const int b_sw = hd2_swz(brow);
+    auto compute_step = [&](int slot, int k0) {
+        const char* wl = smem + slot * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = kk * 2 + frag_half;
+            half8_t bf = *reinterpret_cast<const half8_t*>(wl + b_off + ((chunk ^ b_sw) << 4));
+            const half8_t sc = *reinterpret_cast<const half8_t*>(pro_lds + k0 + chunk * 8);
+            const half8_t sh = *reinterpret_cast<const half8_t*>(pro_lds + 2048 + k0 + chunk * 8);
+            const half8_t z = {};
+            bf = __builtin_elementwise_max(bf * sc + sh, z);      // postnorm BN + ReLU, fp16 FMA (resnet_v2.py:229)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = i * 32 + frag_row;
+                const half8_t af = *reinterpret_cast<const half8_t*>(wl + row * ROW_BYTES + ((chunk ^ hd2_swz(row)) << 4));
+#ifndef METRO_DBG_HD2_NO_MFMA
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[i], 0, 0, 0);
+#else
+                acc[i][0] += (float)af[0] * (float)bf[0];
+#endif
+            }
+        }
+    };
+    // steady state: the three younger steps stay in flight (counted per wave: 4 or 3 DMA instructions per step)
+    const int n_main = nk - (STAGES - 1);
+    int slot = 0, islot = STAGES - 1;
+    for (int k = 0; k < n_main; ++k) {
+        if (na == 2) hd_wait_barrier<3 * 4>(); else hd_wait_barrier<3 * 3>();
+        issue_step(islot);
+        compute_step(slot, k * BK);
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+        islot = islot + 1 == STAGES ? 0 : islot + 1;
+    }
+    for (int k = n_main < 0 ? 0 : n_main; k < nk; ++k) {      // drain
+        const int ahead = nk - 1 - k;
+        if (ahead >= 3) { if (na == 2) hd_wait_barrier<12>(); else hd_wait_barrier<9>(); }
+        else if (ahead == 2) { if (na == 2) hd_wait_barrier<8>(); else hd_wait_barrier<6>(); }
+        else if (ahead == 1) { if (na == 2) hd_wait_barrier<4>(); else hd_wait_barrier<3>(); }
+        else hd_wait_barrier<0>();
+        compute_step(slot, k * BK);
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+    __syncthreads();      // every wave is done with the ring: the logits tile overlays it
+
+    // ---- per-joint softmax statistics, one record per (image, 32-pixel slab, joint): every wave works on ITS OWN 32 pixels.
+    //      (First version: four 64-pixel chunks through one shared logits tile, joints dealt to waves, lanes = pixels: 40 of the
+    //      launch's 98 us -- two barriers per chunk, six of eight waves idle while two write, serial 64-lane folds.)
+    //      The wave's fp32 logits (+ bias) go to a wave-private LDS tile [32 pixels][161]; lane (pixel = lane & 31, half) then takes
+    //      joints half, half + 2, ...: exact two-pass softmax over the group's 32 x D voxels, folds across the 32 lanes of its half
+    //      with xor shuffles 16 .. 1 (never crossing halves).  Two rounds (waves 0-3, then 4-7) share four tile regions.
+    float* lt = reinterpret_cast<float*>(smem) + (wave & 3) * (32 * LROW);
+    const float step_s = 1.0f / (float)(a.side - 1);
+    const float step_d = 1.0f / (float)(a.D - 1);
+#ifdef METRO_DBG_HD2_NO_SOFTMAX
+    if (a.J > 0) { if (tid == 0) a.partials[0] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + acc[4][4]; return; }
+#endif
+    for (int round = 0; round < 2; ++round) {
+        if ((wave >> 2) == round) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = i * 32 + 8 * q + 4 * frag_half;
+                    floatx4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (c0 < a.C) bv = *reinterpret_cast<const floatx4*>(a.bias + c0);      // C % 4 == 0 (plan)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lt[frag_row * LROW + c0 + e] = acc[i][4 * q + e] + bv[e];
+                }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the wave's own LDS writes are complete
+            if (a.logits_out != nullptr) {
+                for (int idx = lane; idx < 32 * a.C; idx += 64) {
+                    const int p = idx / a.C, c = idx - p * a.C;
+                    a.logits_out[(size_t)(m0 + wave * 32 + p) * a.C + c] = lt[p * LROW + c];
+                }
+            }
+            const int pim = tile * TN + wave * 32 + frag_row;     // pixel index inside the image
+            const int py = pim / a.side, px = pim - py * a.side;
+            const float cx = (float)px * step_s, cy = (float)py * step_s;
+            const int slab = tile * (TN / 32) + wave;
+            for (int j = frag_half; j < a.J; j += 2) {
+                float m = -INFINITY;
+                for (int d = 0; d < a.D; ++d) m = fmaxf(m, lt[frag_row * LROW + d * a.J + j]);
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                float s = 0.f, sz = 0.f;
+                for (int d = 0; d < a.D; ++d) {
+                    const float e = __expf(lt[frag_row * LROW + d * a.J + j] - m);
+                    s += e;
+                    sz += e * ((float)d * step_d);
+                }
+                float sx = s * cx, sy = s * cy;
+#pragma unroll
+                for (int o = 16; o >= 1; o >>= 1) {
+                    s += __shfl_xor(s, o, 64);
+                    sx += __shfl_xor(sx, o, 64);
+                    sy += __shfl_xor(sy, o, 64);
+                    sz += __shfl_xor(sz, o, 64);
+                }
+                if (frag_row == 0) {
+                    float* o5 = a.partials + (((size_t)img * a.slabs + slab) * a.J + j) * 5;
+                    o5[0] = m; o5[1] = s; o5[2] = sx; o5[3] = sy; o5[4] = sz;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // heads this launch is built for: fp16 input, whole 128-pixel slabs per image, at most 160 channels, K in whole steps
 bool head_f16_supported(int c_in, int c_head, int n_joints, int depth, int side) {
     static const int enabled = tuning_knob("METRO_HEAD_FUSED", 1);
@@ -245,7 +444,15 @@ bool head_f16_supported(int c_in, int c_head, int n_joints, int depth, int side)
     return enabled && c_head == n_joints * depth && c_head <= hd::TM && c_in % hd::BK == 0 && c_in <= 2048 &&
            c_in / hd::BK >= hd::STAGES - 1 && pixels % hd::TN == 0 && side >= 2 && depth >= 2;
 }
-int head_f16_slabs(int side) { return side * side / hd::TN; }
+// 256-pixel tiles once they still give every CU a tile
+static bool head_f16_big(int n, int side) {
+    static const int t256 = tuning_knob("METRO_HEAD_256", 1);
+    return t256 && (side * side) % hd2::TN == 0 && (long)n * (side * side / hd2::TN) >= 256;
+}
+// records per image: one per 64 pixels (64-pixel tiles) or per 32 (256-pixel tiles); the partials slot is sized for the larger
+int head_f16_slabs(int side) { return side * side / 32; }
+// ... and what a launch at batch n writes (= what softargmax_finalize must fold)
+int head_f16_records(int n, int side) { return head_f16_big(n, side) ? side * side / 32 : side * side / hd::TN; }
 
 int launch_head_f16(const void* x, const void* w, const float* bias, const void* pro_scale, const void* pro_shift,
                     int n, int c_in, int c_head, int n_joints, int depth, int side, float* partials, float* logits_out,
@@ -254,12 +461,20 @@ int launch_head_f16(const void* x, const void* w, const float* bias, const void*
         set_error("head_f16: unsupported head (c_in %d, %d channels = %d joints x depth %d, side %d)", c_in, c_head, n_joints, depth, side);
         return METRO_ERR_UNSUPPORTED;
     }
-    if (note_kernel("head_f16<160x64>")) return METRO_OK;
+    const bool big = head_f16_big(n, side);
+    if (note_kernel(big ? "head_f16<160x256>" : "head_f16<160x64>")) return METRO_OK;
     HeadArgs a;
     a.x = static_cast<const half_t*>(x); a.w = static_cast<const half_t*>(w); a.bias = bias;
     a.pro_scale = static_cast<const half_t*>(pro_scale); a.pro_shift = static_cast<const half_t*>(pro_shift);
     a.partials = partials; a.logits_out = logits_out;
-    a.K = c_in; a.C = c_head; a.J = n_joints; a.D = depth; a.side = side; a.pixels = side * side; a.slabs = head_f16_slabs(side);
+    a.K = c_in; a.C = c_head; a.J = n_joints; a.D = depth; a.side = side; a.pixels = side * side;
+    a.slabs = head_f16_records(n, side);
+    if (big) {
+        static PerDeviceInt done2;
+        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(head_f16_kernel256), hd2::LDS_BYTES, done2, "head_f16<256>")) return st;
+        hipLaunchKernelGGL(head_f16_kernel256, dim3(side * side / hd2::TN, n), dim3(hd2::NT), hd2::LDS_BYTES, stream, a);
+        return launch_status("head_f16<256>");
+    }
     static PerDeviceInt done;
     if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(head_f16_kernel), hd::LDS_BYTES, done, "head_f16")) return st;
     hipLaunchKernelGGL(head_f16_kernel, dim3(a.slabs, n), dim3(hd::NT), hd::LDS_BYTES, stream, a);

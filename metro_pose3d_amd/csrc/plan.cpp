@@ -679,7 +679,7 @@ int launch_layer(MetroPlan* p, int li, const float* images, int n, float* poses,
             if (poses == nullptr) { set_error("metro_forward: poses_out is NULL"); return METRO_ERR_INVALID_ARG; }
             const SoftArgmaxArgs a = make_softargmax_args(p->spec, n);
             if (L.head_fused)
-                return launch_softargmax_finalize(static_cast<const float*>(slot_ptr(S_PART)), a, head_f16_slabs(a.side), poses, stream);
+                return launch_softargmax_finalize(static_cast<const float*>(slot_ptr(S_PART)), a, head_f16_records(n, a.side), poses, stream);
             return launch_softargmax(slot_ptr(L.in_slot), a, p->spec.precision, slot_ptr(S_PART), poses, stream);
         }
     }
@@ -1079,7 +1079,7 @@ int metro_head_f16(const void* d_x, const void* d_w, const float* d_bias, const 
                              spec->n_joints_head, spec->depth, side, static_cast<float*>(d_partials), d_logits_out,
                              static_cast<hipStream_t>(stream));
     if (st) return st;
-    return launch_softargmax_finalize(static_cast<const float*>(d_partials), a, head_f16_slabs(side), d_poses_out,
+    return launch_softargmax_finalize(static_cast<const float*>(d_partials), a, head_f16_records(n, side), d_poses_out,
                                       static_cast<hipStream_t>(stream));
 }
 

@@ -301,40 +301,59 @@ __global__ __launch_bounds__(SA_NT) void softargmax_partial_kernel(
     }
 }
 
+// One block of four waves per image; wave w folds joints w, w + 4, ...: its lanes stride over the slabs (up to 128 records per
+// joint behind the 256-pixel head), maximum and the four rescaled sums folded across the wave with xor shuffles in a fixed
+// order -- a serial loop over the slabs by ONE thread per joint cost 20 us on a 64 x 64 heat map.
 template <typename AccT>
-__global__ __launch_bounds__(64) void softargmax_finalize_kernel(const AccT* __restrict__ partials,
-                                                                 float* __restrict__ poses,
-                                                                 SoftArgmaxArgs a, int slabs,
-                                                                 float* __restrict__ coords01) {
+__device__ __forceinline__ AccT sa_wave_sum(AccT v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename AccT>
+__global__ __launch_bounds__(256) void softargmax_finalize_kernel(const AccT* __restrict__ partials,
+                                                                  float* __restrict__ poses,
+                                                                  SoftArgmaxArgs a, int slabs,
+                                                                  float* __restrict__ coords01) {
     __shared__ AccT mm[METRO_MAX_JOINTS][3];
     const int img = blockIdx.x;
-    const int j = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nj = a.n_joints_head;
-    if (j < nj) {
+    for (int j = wave; j < nj; j += 4) {
         AccT M = (AccT)-INFINITY;
-        for (int sl = 0; sl < slabs; ++sl) {
+        for (int sl = lane; sl < slabs; sl += 64) {
             const AccT mv = partials[(((size_t)img * slabs + sl) * nj + j) * 5];
             M = mv > M ? mv : M;
         }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const AccT other = __shfl_xor(M, o, 64);
+            M = other > M ? other : M;
+        }
         AccT S = 0, SX = 0, SY = 0, SZ = 0;
-        for (int sl = 0; sl < slabs; ++sl) {
+        for (int sl = lane; sl < slabs; sl += 64) {
             const AccT* r = partials + (((size_t)img * slabs + sl) * nj + j) * 5;
             if (r[1] > 0) {
                 const AccT f = acc_exp<AccT>(r[0] - M);
                 S += r[1] * f; SX += r[2] * f; SY += r[3] * f; SZ += r[4] * f;
             }
         }
-        const AccT x01 = SX / S, y01 = SY / S, z01 = SZ / S;
-        if (coords01 != nullptr) {            // net_output_to_heatmap_and_coords output (volumetric.py:234-235)
-            float* c = coords01 + ((size_t)img * nj + j) * 3;
-            c[0] = (float)x01; c[1] = (float)y01; c[2] = (float)z01;
+        S = sa_wave_sum(S); SX = sa_wave_sum(SX); SY = sa_wave_sum(SY); SZ = sa_wave_sum(SZ);
+        if (lane == 0) {
+            const AccT x01 = SX / S, y01 = SY / S, z01 = SZ / S;
+            if (coords01 != nullptr) {            // net_output_to_heatmap_and_coords output (volumetric.py:234-235)
+                float* c = coords01 + ((size_t)img * nj + j) * 3;
+                c[0] = (float)x01; c[1] = (float)y01; c[2] = (float)z01;
+            }
+            // heatmap_to_metric: (c * lrc + half) * box / proc_side ; z * box  (volumetric.py:288-306)
+            mm[j][0] = (x01 * (AccT)a.lrc + (AccT)a.half_off) * (AccT)a.box_size_mm / (AccT)a.proc_side;
+            mm[j][1] = (y01 * (AccT)a.lrc + (AccT)a.half_off) * (AccT)a.box_size_mm / (AccT)a.proc_side;
+            mm[j][2] = z01 * (AccT)a.box_size_mm;
         }
-        // heatmap_to_metric: (c * lrc + half) * box / proc_side ; z * box  (volumetric.py:288-306)
-        mm[j][0] = (x01 * (AccT)a.lrc + (AccT)a.half_off) * (AccT)a.box_size_mm / (AccT)a.proc_side;
-        mm[j][1] = (y01 * (AccT)a.lrc + (AccT)a.half_off) * (AccT)a.box_size_mm / (AccT)a.proc_side;
-        mm[j][2] = z01 * (AccT)a.box_size_mm;
     }
     __syncthreads();
+    const int j = threadIdx.x;
     if (poses != nullptr && j < a.n_joints_out) {
         const int src = a.perm[j];
         float* o = poses + ((size_t)img * a.n_joints_out + j) * 3;
@@ -379,7 +398,7 @@ static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void
                        static_cast<AccT*>(partials), a.side, a.depth, a.n_joints_head, slabs);
     int st = launch_status("softargmax_partial");
     if (st) return st;
-    hipLaunchKernelGGL(softargmax_finalize_kernel<AccT>, dim3(a.n), dim3(64), 0, stream,
+    hipLaunchKernelGGL(softargmax_finalize_kernel<AccT>, dim3(a.n), dim3(256), 0, stream,
                        static_cast<const AccT*>(partials), poses, a, slabs, coords01);
     return launch_status("softargmax_finalize");
 }
@@ -387,7 +406,7 @@ static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void
 int launch_softargmax_finalize(const float* partials, const SoftArgmaxArgs& a, int slabs, float* poses_out,
                                hipStream_t stream, float* coords01_out) {
     if (note_kernel("softargmax_finalize<acc32>")) return METRO_OK;
-    hipLaunchKernelGGL(softargmax_finalize_kernel<float>, dim3(a.n), dim3(64), 0, stream, partials, poses_out, a, slabs, coords01_out);
+    hipLaunchKernelGGL(softargmax_finalize_kernel<float>, dim3(a.n), dim3(256), 0, stream, partials, poses_out, a, slabs, coords01_out);
     return launch_status("softargmax_finalize");
 }
 
