@@ -86,12 +86,16 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     const int piece_stride = 32 * K * 2;                               // bytes
 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 ra[PIECES], rb[PIECES];                                      // one staged K tile
-    auto load_tile = [&](int kt) {
+#ifndef METRO_G4_DEPTH
+#define METRO_G4_DEPTH 1     // 2 (a second staged tile, three tiles of lead) measured the same: the loads are not late
+#endif
+    constexpr int DEPTH = METRO_G4_DEPTH;                              // staged K tiles in registers: tile k lives in set k % DEPTH
+    u32x4 ra[DEPTH][PIECES], rb[DEPTH][PIECES];
+    auto load_tile = [&](int set, int kt) {
 #pragma unroll
         for (int e = 0; e < PIECES; ++e) {
-            ra[e] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, e * piece_stride + kt * BK * 2, 0);
-            rb[e] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, e * piece_stride + kt * BK * 2, 0);
+            ra[set][e] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, e * piece_stride + kt * BK * 2, 0);
+            rb[set][e] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, e * piece_stride + kt * BK * 2, 0);
         }
     };
     // pre-activation BN + ReLU on a staged pixel chunk (fp16 FMA, one rounding: resnet_v2.py:119); a lane's chunk is always
@@ -103,15 +107,15 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
             pro_sh = *reinterpret_cast<const half8_t*>(pro_lds + 2048 + kt * BK + lch * 8);
         }
     };
-    auto store_piece = [&](int buf, int e) {
-        *reinterpret_cast<u32x4*>(smem + A_OFF + buf * OPER_BYTES + st_off + e * 32 * ROW_BYTES) = ra[e];
+    auto store_piece = [&](int buf, int set, int e) {
+        *reinterpret_cast<u32x4*>(smem + A_OFF + buf * OPER_BYTES + st_off + e * 32 * ROW_BYTES) = ra[set][e];
         if constexpr (PROLOGUE) {
             const half8_t z = {};
-            half8_t x = *reinterpret_cast<const half8_t*>(&rb[e]);
+            half8_t x = *reinterpret_cast<const half8_t*>(&rb[set][e]);
             x = __builtin_elementwise_max(x * pro_sc + pro_sh, z);
             *reinterpret_cast<half8_t*>(smem + B_OFF + buf * OPER_BYTES + st_off + e * 32 * ROW_BYTES) = x;
         } else {
-            *reinterpret_cast<u32x4*>(smem + B_OFF + buf * OPER_BYTES + st_off + e * 32 * ROW_BYTES) = rb[e];
+            *reinterpret_cast<u32x4*>(smem + B_OFF + buf * OPER_BYTES + st_off + e * 32 * ROW_BYTES) = rb[set][e];
         }
     };
 
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     }
 
     // ---- prologue: table, tile 0 -> LDS buffer 0, tile 1 -> registers -----------------------------------------------
-    load_tile(0);
+    load_tile(0, 0);
     if (PROLOGUE) {
         for (int c = tid * 8; c < K; c += NT * 8) {
             *reinterpret_cast<uint4*>(pro_lds + c) = *reinterpret_cast<const uint4*>(pro_scale + c);
@@ -147,8 +151,9 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     }
     load_pro(0);
 #pragma unroll
-    for (int e = 0; e < PIECES; ++e) store_piece(0, e);
-    load_tile(nk > 1 ? 1 : 0);
+    for (int e = 0; e < PIECES; ++e) store_piece(0, 0, e);
+    load_tile(1 % DEPTH, nk > 1 ? 1 : 0);                 // tile 1 (and, two deep, tile 2) wait in registers
+    if (DEPTH == 2) load_tile(0, nk > 2 ? 2 : nk - 1);
     __syncthreads();
 
     half8_t af[2][4], bf[2][4];          // two fragment sets: the k step being multiplied and the next one
@@ -175,8 +180,9 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     auto ktile = [&](auto buf_c, int kt) {
         constexpr int BUF = decltype(buf_c)::value;
         const int kt1 = kt + 1 < nk ? kt + 1 : nk - 1;
-        const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;
+        const int kt2 = kt + 1 + DEPTH < nk ? kt + 1 + DEPTH : nk - 1;       // the tile requested into the set that is written now
         const int knext = kt2 * BK * 2;
+        constexpr int SET = DEPTH == 2 ? (BUF ^ 1) : 0;                       // tile kt + 1 (kt even <=> BUF 0: the K loop is unrolled by two)
         load_pro(kt1);
         auto step = [&](auto kk_c) {
             constexpr int kk = decltype(kk_c)::value;
@@ -185,13 +191,13 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
             load_frags((kk + 1) & 1, BUF, kk + 1);
 #ifndef METRO_DBG_G4_NO_WRITE
 #pragma unroll
-            for (int e = first[kk]; e < first[kk + 1]; ++e) store_piece(BUF ^ 1, e);
+            for (int e = first[kk]; e < first[kk + 1]; ++e) store_piece(BUF ^ 1, SET, e);
 #endif
 #ifndef METRO_DBG_G4_NO_LOAD
 #pragma unroll
             for (int e = first[kk]; e < first[kk + 1]; ++e) {
-                ra[e] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, e * piece_stride + knext, 0);
-                rb[e] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, e * piece_stride + knext, 0);
+                ra[SET][e] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, e * piece_stride + knext, 0);
+                rb[SET][e] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, e * piece_stride + knext, 0);
             }
 #endif
 #ifndef METRO_DBG_G4_NO_MFMA

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     using namespace pw;
     using L = Lay<K, WM, CB>;
     static_assert((WM == 4 && K <= 128) || (WM == 8 && K <= 512), "weights must fit the register file as MFMA fragments");
-    static_assert(CB == 256 || (CB == 512 && (K == 128 || (K == 256 && MODE2 == 0)) && WM == 8 && RES && !PRO && !RSUB), "512-channel blocks: conv3 of blocks 2-3");
+    static_assert(CB == 256 || (CB == 512 && K == 128 && WM == 8 && RES && !PRO && !RSUB), "512-channel blocks: conv3 of block2");
     static_assert(MODE2 == 0 || (K == 64 && WM == 4) || (MODE2 == 2 && CB == 512), "second outputs: block1 shapes, or conv3 + next conv1 of block2");
     static_assert(!PSC || (MODE2 == 2 && !PRO && !RES), "in-launch projection shortcut: conv3 + next conv1 of block1/unit_1");
     constexpr int KK = K / 16, WN = L::WN, NI = L::NI, TN = L::TN, XI = L::XI, RI = L::RI;
@@ -534,11 +534,7 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
         return launch_pw<64, 4, false, true, 2>(a, stream);
     }
     if (d.c_in == 512) return launch_pw<512, 8, false, true, 0>(a, stream);
-    if (d.c_in == 256) {
-        static const int cb512 = pw_env_int("METRO_PW_K256_CB512", 0);
-        if (cb512 && !rsub) return launch_pw<256, 8, false, true, 0, false, false, 512>(a, stream);
-        return launch_pw<256, 8, false, true, 0>(a, stream);
-    }
+    if (d.c_in == 256) return launch_pw<256, 8, false, true, 0>(a, stream);
     if (d.c_in == 128) return rsub ? launch_pw<128, 4, false, true, 0, true>(a, stream) : launch_pw<128, 4, false, true, 0>(a, stream);
     if (d.has_prologue) return launch_pw<64, 4, true, false, 0>(a, stream);
     return rsub ? launch_pw<64, 4, false, true, 0, true>(a, stream) : launch_pw<64, 4, false, true, 0>(a, stream);
