@@ -61,7 +61,7 @@ def parse_args():
     ap.add_argument('--stride', type=int, default=16)
     ap.add_argument('--dataset', type=str, default=None,
                     help='default: h36m (17 joints, configs[1]) on 1 GPU, many19 (19 joints, configs[2]) on N > 1')
-    ap.add_argument('--precision', type=str, default='f16', choices=['f16', 'f32', 'f64'])
+    ap.add_argument('--precision', type=str, default='f16', choices=['f16', 'f32', 'f32m', 'f64'])
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg (0 = skip)')
     ap.add_argument('--cpu-crops', type=int, default=8)
     ap.add_argument('--layer-report', type=str, default=None, help='write the per-layer table to this file')
@@ -397,7 +397,7 @@ def main():
             'value': round(value, 2), 'unit': 'crops/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'f16': 'f16', 'f32': 'f32 storage, f64 accumulate', 'f64': 'f64'}[args.precision],
+            'dtype': {'f16': 'f16', 'f32': 'f32 storage, f64 accumulate', 'f32m': 'f32 (fp32 MFMA)', 'f64': 'f64'}[args.precision],
             'data': 'ALL-ZERO weights and crops: DIAGNOSTIC RUN, NOT A RESULT' if args.diag_zero_data else
                     'synthetic (seeded random weights + uniform [0,1) crops; no released weights offline)',
             'config': {'workload': f'RN{args.arch}-s{args.stride}-J{spec.skeleton.n_head} {dataset}, '
@@ -442,6 +442,23 @@ def main():
         out['parity_mode'] = {'precision': 'f64 (fp64 MFMA, fp64 storage)', 'crops_per_s': round(b * psteps / (pms * 1e-3), 1),
                               'ms_per_step': round(pms / psteps, 3), 'steps': psteps}
         del eng64
+        # the parity mode at fp32 speed: fp32 matrix cores (v_mfma_f32_32x32x2_f32), fp32 storage -- the arithmetic of the
+        # reference's own fp32 graph; its distance to the fp64 oracle next to the CPU fp32 restatement's distance (two correct
+        # fp32 implementations differ from exact math by this much; the 1e-3 mm bar is met by the f64 mode only)
+        eng32 = Engine(spec, params, 'f32m', max_batch=b, device=device)
+        out32 = torch.empty_like(local)
+        eng32.forward(images, out=out32)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            cpu32 = OF.forward(ospec, params, images_np[:k], torch.float32).numpy().astype(np.float64)
+        msteps = 5
+        _, mms, _ = timed_steps(lambda: eng32.forward(images, out=out32), msteps, device, 1, dist)
+        out['parity_mode_fp32'] = {'precision': 'f32m (fp32 MFMA v_mfma_f32_32x32x2_f32, fp32 storage, fp64 soft-argmax)',
+                                   'crops_per_s': round(b * msteps / (mms * 1e-3), 1), 'ms_per_step': round(mms / msteps, 3), 'steps': msteps,
+                                   'max_abs_dmm_vs_fp64_oracle': float(f'{np.abs(out32[:k].cpu().numpy() - exact).max():.3e}'),
+                                   'cpu_fp32_restatement_max_abs_dmm_vs_fp64_oracle': float(f'{np.abs(cpu32 - exact).max():.3e}'),
+                                   'tflops': round(eng32.flops_per_image * b * msteps / (mms * 1e-3) / 1e12, 1), 'peak_tflops': 157.3}
+        del eng32
         if not args.diag_zero_data:
             # DVFS diagnostic (not a result): the SAME launches on all-zero weights and crops.  The chip clocks to its
             # power budget (MI355X_MICROARCH.md, "DVFS give-back"); the ratio says how much of the step time is the

@@ -42,8 +42,12 @@ typedef enum MetroStatus {
  *      from fp64-folded weights, fp64 soft-argmax; one rounding to fp32 per layer output.
  *      Sits at the fp32 storage noise floor (~1e-3 mm vs exact arithmetic).
  * F64: as F32 but activations and logits are stored as fp64 too: the parity mode, measured
- *      against the fp64 oracle (bar <= 1e-3 mm; lands orders of magnitude below). */
-typedef enum MetroPrecision { METRO_PREC_F16 = 0, METRO_PREC_F32 = 1, METRO_PREC_F64 = 2 } MetroPrecision;
+ *      against the fp64 oracle (bar <= 1e-3 mm; lands orders of magnitude below).
+ * F32M: the arithmetic of the reference's fp32 graph (--dtype=float32, reference src/options.py:73): fp32 activations, fp32
+ *      (BN-folded) weights, every contraction on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation in ascending
+ *      k), fp64 soft-argmax on the fp32 logits.  The parity mode at fp32 speed: sits AT the noise floor two correct fp32
+ *      implementations have between them (1-5e-3 mm), not under the 1e-3 mm bar. */
+typedef enum MetroPrecision { METRO_PREC_F16 = 0, METRO_PREC_F32 = 1, METRO_PREC_F64 = 2, METRO_PREC_F32M = 3 } MetroPrecision;
 
 typedef enum MetroDType { METRO_F16 = 0, METRO_F32 = 1, METRO_F64 = 2 } MetroDType;
 
@@ -253,6 +257,11 @@ int  metro_conv_f64acc(const MetroConvDesc* d, const void* d_in, const double* d
                        const double* d_bias, const double* d_pro_scale,
                        const double* d_pro_shift, const void* d_residual, void* d_out,
                        void* stream);
+
+/* fp32 activations, fp32 weights / bias / prologue, v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation): the conv
+ * kernel of the METRO_PREC_F32M mode.  in_dtype = out_dtype = METRO_F32; any c_in. */
+int  metro_conv_f32m(const MetroConvDesc* d, const void* d_in, const float* d_w, const float* d_bias, const float* d_pro_scale,
+                     const float* d_pro_shift, const void* d_residual, void* d_out, void* stream);
 
 /* fp32 NHWC [n,side,side,3] -> zero-bordered fp16 [n,side+6,side+8,4] (the stem's explicit
  * pad-3 of reference resnet_utils.py:125-135 materialised once; channel 3 is zero). */

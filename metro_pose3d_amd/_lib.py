@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get('METRO_HIP_LIB') or os.path.join(HERE, 'libmetro_hip.s
 
 METRO_MAX_JOINTS = 64
 ABI_VERSION = 5          # include/metro_hip.h METRO_ABI_VERSION
-METRO_PREC_F16, METRO_PREC_F32, METRO_PREC_F64 = 0, 1, 2
+METRO_PREC_F16, METRO_PREC_F32, METRO_PREC_F64, METRO_PREC_F32M = 0, 1, 2, 3
 METRO_F16, METRO_F32, METRO_F64 = 0, 1, 2
 PARAM_CONV_W, PARAM_BIAS, PARAM_PRO_SCALE, PARAM_PRO_SHIFT = 0, 1, 2, 3
 LAYER_PREP, LAYER_CONV, LAYER_POOL, LAYER_SOFTARGMAX = 0, 1, 2, 3
@@ -78,6 +78,7 @@ SIGNATURES = {
     'metro_forward_upto': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32]),
     'metro_forward_timed': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_float)]),
     'metro_conv_f16': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    'metro_conv_f32m': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f64acc': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f16_pair': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
     'metro_conv_f16_gemm8p': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),

@@ -251,6 +251,9 @@ int launch_conv3x3_slab(const MetroConvDesc& d, const void* in, const void* w, c
 int launch_conv_f64acc(const MetroConvDesc& d, const void* in, const double* w, const double* bias,
                        const double* pro_scale, const double* pro_shift, const void* residual,
                        void* out, hipStream_t stream);
+// fp32 conv on the fp32 matrix cores (conv_igemm_f32.hip): METRO_PREC_F32M
+int launch_conv_f32m(const MetroConvDesc& d, const void* in, const float* w, const float* bias, const float* pro_scale,
+                     const float* pro_shift, const void* residual, void* out, hipStream_t stream);
 int launch_prep_input_f16(const float* images, int n, int side, void* out, hipStream_t stream);
 int launch_warp_crop_u8(const unsigned char* img, int h, int w, int row_stride, const float* homs, float* out,
                         int n, int side, hipStream_t stream);

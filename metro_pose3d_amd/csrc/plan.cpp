@@ -173,8 +173,9 @@ struct Builder {
         L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE;
         L.kind = LK_CONV;
         const bool fast = p->fast;
-        const int wdt = fast ? METRO_F16 : METRO_F64;
-        const int bdt = fast ? METRO_F32 : METRO_F64;
+        const bool f32m = p->spec.precision == METRO_PREC_F32M;
+        const int wdt = fast ? METRO_F16 : f32m ? METRO_F32 : METRO_F64;
+        const int bdt = fast || f32m ? METRO_F32 : METRO_F64;
         MetroConvDesc& cd = L.cd;
         cd.n = 0;
         cd.h_in = cd.w_in = side_in; cd.c_in = c_in; cd.in_pix_stride = c_in;
@@ -671,6 +672,10 @@ int launch_layer(MetroPlan* p, int li, const float* images, int n, float* poses,
             if (p->fast)
                 return launch_conv_f16(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
                                        prm(L.p_scale), prm(L.p_shift), slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream);
+            if (p->spec.precision == METRO_PREC_F32M)
+                return launch_conv_f32m(cd, slot_ptr(L.in_slot), static_cast<const float*>(prm(L.p_w)), static_cast<const float*>(prm(L.p_bias)),
+                                        static_cast<const float*>(prm(L.p_scale)), static_cast<const float*>(prm(L.p_shift)),
+                                        slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream);
             return launch_conv_f64acc(cd, slot_ptr(L.in_slot), static_cast<const double*>(prm(L.p_w)),
                                       static_cast<const double*>(prm(L.p_bias)), static_cast<const double*>(prm(L.p_scale)),
                                       static_cast<const double*>(prm(L.p_shift)), slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream);
@@ -680,7 +685,8 @@ int launch_layer(MetroPlan* p, int li, const float* images, int n, float* poses,
             const SoftArgmaxArgs a = make_softargmax_args(p->spec, n);
             if (L.head_fused)
                 return launch_softargmax_finalize(static_cast<const float*>(slot_ptr(S_PART)), a, head_f16_records(n, a.side), poses, stream);
-            return launch_softargmax(slot_ptr(L.in_slot), a, p->spec.precision, slot_ptr(S_PART), poses, stream);
+            // precise: 0 fp32 / fp32, 1 fp32 logits + fp64 accumulators (F32 and F32M modes), 2 fp64 / fp64
+            return launch_softargmax(slot_ptr(L.in_slot), a, p->spec.precision == METRO_PREC_F32M ? 1 : p->spec.precision, slot_ptr(S_PART), poses, stream);
         }
     }
     set_error("internal: layer %d has unknown kind %d", li, L.kind);
@@ -741,7 +747,8 @@ int metro_plan_create(const MetroSpec* spec, int32_t max_batch, MetroPlan** out_
         METRO_CHECK_ARG(spec->permutation[i] >= 0 && spec->permutation[i] < spec->n_joints_head,
                         "permutation[%d] = %d outside the head's %d joints", i, spec->permutation[i], spec->n_joints_head);
     METRO_CHECK_ARG((spec->depth * spec->n_joints_head) % 4 == 0, "depth*n_joints_head must be a multiple of 4");
-    METRO_CHECK_ARG(spec->precision == METRO_PREC_F16 || spec->precision == METRO_PREC_F32 || spec->precision == METRO_PREC_F64, "unknown precision %d", spec->precision);
+    METRO_CHECK_ARG(spec->precision == METRO_PREC_F16 || spec->precision == METRO_PREC_F32 || spec->precision == METRO_PREC_F64 ||
+                        spec->precision == METRO_PREC_F32M, "unknown precision %d", spec->precision);
     METRO_CHECK_ARG(spec->base_width >= 8 && spec->base_width % 8 == 0, "base_width %d must be a positive multiple of 8", spec->base_width);
     METRO_CHECK_ARG(max_batch >= 1 && max_batch <= 4096, "max_batch %d out of range", max_batch);
     METRO_CHECK_ARG(spec->box_size_mm > 0.f, "box_size_mm must be positive");
@@ -750,8 +757,9 @@ int metro_plan_create(const MetroSpec* spec, int32_t max_batch, MetroPlan** out_
     p->spec = *spec;
     p->max_batch = max_batch;
     p->fast = spec->precision == METRO_PREC_F16;
-    p->act_dtype = p->fast ? METRO_F16 : spec->precision == METRO_PREC_F32 ? METRO_F32 : METRO_F64;
-    p->act_bytes = p->fast ? 2 : spec->precision == METRO_PREC_F32 ? 4 : 8;
+    const bool f32_store = spec->precision == METRO_PREC_F32 || spec->precision == METRO_PREC_F32M;
+    p->act_dtype = p->fast ? METRO_F16 : f32_store ? METRO_F32 : METRO_F64;
+    p->act_bytes = p->fast ? 2 : f32_store ? 4 : 8;
     for (int s = 0; s < S_COUNT; ++s) { p->slot_bytes_per_image[s] = 0; p->slot_offset[s] = 0; }
     p->workspace_bytes = 0; p->param_bytes = 0; p->d_params = nullptr; p->flops_per_image = 0.0;
     const int st = build_plan(p);
@@ -1017,6 +1025,17 @@ int metro_conv_f64acc(const MetroConvDesc* d, const void* d_in, const double* d_
     METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f64acc: residual tensor missing");
     return launch_conv_f64acc(*d, d_in, d_w, d_bias, d_pro_scale, d_pro_shift, d_residual, d_out,
                               static_cast<hipStream_t>(stream));
+}
+
+int metro_conv_f32m(const MetroConvDesc* d, const void* d_in, const float* d_w, const float* d_bias, const float* d_pro_scale,
+                    const float* d_pro_shift, const void* d_residual, void* d_out, void* stream) {
+    int st = validate_conv_desc(d);
+    if (st) return st;
+    METRO_CHECK_ARG(d->in_dtype == METRO_F32 && d->out_dtype == METRO_F32, "conv_f32m: in/out dtypes must be F32");
+    METRO_CHECK_ARG(d_in && d_w && d_bias && d_out, "conv_f32m: NULL tensor pointer");
+    METRO_CHECK_ARG(!d->has_prologue || (d_pro_scale && d_pro_shift), "conv_f32m: prologue tensors missing");
+    METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f32m: residual tensor missing");
+    return launch_conv_f32m(*d, d_in, d_w, d_bias, d_pro_scale, d_pro_shift, d_residual, d_out, static_cast<hipStream_t>(stream));
 }
 
 int metro_prep_input_f16(const float* d_images, int32_t n, int32_t side, void* d_out, void* stream) {

@@ -17,7 +17,7 @@ from metro_pose3d_amd.spec import ModelSpec
 BN_EPS = 1e-5   # reference src/model/architectures.py:10
 
 _NP_DTYPE = {_lib.METRO_F16: np.float16, _lib.METRO_F32: np.float32, _lib.METRO_F64: np.float64}
-_PRECISIONS = {'f16': _lib.METRO_PREC_F16, 'f32': _lib.METRO_PREC_F32, 'f64': _lib.METRO_PREC_F64}
+_PRECISIONS = {'f16': _lib.METRO_PREC_F16, 'f32': _lib.METRO_PREC_F32, 'f64': _lib.METRO_PREC_F64, 'f32m': _lib.METRO_PREC_F32M}
 
 
 def _bn_scale_shift(params: Dict[str, np.ndarray], bn: str):
@@ -67,7 +67,7 @@ class Engine:
     def __init__(self, spec: ModelSpec, params: Optional[Dict[str, np.ndarray]],
                  precision: str = 'f16', max_batch: int = 64, device: Optional[torch.device] = None):
         if precision not in _PRECISIONS:
-            raise ValueError(f"precision must be 'f16', 'f32' or 'f64', got {precision!r}")
+            raise ValueError(f"precision must be 'f16', 'f32', 'f32m' or 'f64', got {precision!r}")
         self.lib = _lib.load()
         self.spec = spec
         self.precision = precision

@@ -42,6 +42,12 @@ def test_toy_forward_parity_within_1e3_mm(cuda, spec):
         got = Engine(spec, params, prec, max_batch=4, device=cuda).forward(x).cpu().numpy()
         assert np.isfinite(got).all()
         assert np.abs(got - ref).max() <= tol, (prec, np.abs(got - ref).max())
+    # the fp32-matrix-core mode accumulates in fp32 like the reference's fp32 graph: held to the distance the CPU fp32
+    # restatement of the same graph has to exact math (two samples of the same rounding noise: 3x on the maximum of 51-57 values)
+    got = Engine(spec, params, 'f32m', max_batch=4, device=cuda).forward(x).cpu().numpy()
+    cpu32 = OF.forward(H.oracle_spec(spec), params, images, torch.float32).numpy().astype(np.float64)
+    e, ec = np.abs(got - ref).max(), np.abs(cpu32 - ref).max()
+    assert np.isfinite(got).all() and e <= max(3.0 * ec, 2e-3), ('f32m', e, ec)
 
 
 @pytest.mark.parametrize('spec', TOY[:3], ids=_id)
@@ -51,7 +57,7 @@ def test_toy_layerwise(cuda, spec):
     col = {}
     OF.forward(H.oracle_spec(spec), params, images, torch.float64, col)
     x = torch.from_numpy(images).to(cuda)
-    for prec, rel in (('f64', 1e-11), ('f32', 2e-6), ('f16', 3e-2)):
+    for prec, rel in (('f64', 1e-11), ('f32', 2e-6), ('f32m', 2e-5), ('f16', 3e-2)):
         eng = Engine(spec, params, prec, max_batch=2, device=cuda)
         for i, li in enumerate(eng.layer_infos()):
             name = li.name.decode()
@@ -150,6 +156,14 @@ def test_full_rn50_s16_all_modes(cuda):
     assert np.abs(got64 - ref).max() <= TOL_PARITY_MM, np.abs(got64 - ref).max()
     got32 = Engine(spec, params, 'f32', max_batch=2, device=cuda).forward(x).cpu().numpy()
     assert np.abs(got32 - ref).max() <= TOL_F32_STORAGE_MM, np.abs(got32 - ref).max()
+    # the fp32-speed parity mode (fp32 matrix cores, fp32 storage: the arithmetic of the reference's fp32 graph) is as close to
+    # exact math as the CPU fp32 restatement of the graph is: two correct fp32 implementations, two samples of the same rounding
+    # noise (maximum of 51 values per crop within 2.5x, mean within 2x)
+    got32m = Engine(spec, params, 'f32m', max_batch=2, device=cuda).forward(x).cpu().numpy()
+    cpu32 = OF.forward(H.oracle_spec(spec), params, images, torch.float32).numpy().astype(np.float64)
+    e32m, ecpu = np.abs(got32m - ref), np.abs(cpu32 - ref)
+    print(f'\nf32m mode: max {e32m.max():.2e} mean {e32m.mean():.2e} mm; CPU fp32 restatement: max {ecpu.max():.2e} mean {ecpu.mean():.2e} mm')
+    assert e32m.max() <= max(2.5 * ecpu.max(), 2e-3) and e32m.mean() <= max(2.0 * ecpu.mean(), 5e-4), (e32m.max(), ecpu.max(), e32m.mean(), ecpu.mean())
     got16 = Engine(spec, params, 'f16', max_batch=2, device=cuda).forward(x).cpu().numpy()
     assert np.isfinite(got16).all()
     # fp16 activations (rel 5e-4 per layer over 50+ layers) cost a few mm; the f16 mode must be as accurate as the
@@ -165,7 +179,7 @@ def test_batch_independence_bit_exact(cuda):
     spec = ModelSpec(50, 16, 'h36m', base_width=16)
     params, images = _setup(spec, 6)
     x = torch.from_numpy(images).to(cuda)
-    for prec in ('f16', 'f32', 'f64'):
+    for prec in ('f16', 'f32', 'f32m', 'f64'):
         eng = Engine(spec, params, prec, max_batch=8, device=cuda)
         whole = eng.forward(x).clone()
         parts = torch.cat([eng.forward(x[:2]).clone(), eng.forward(x[2:]).clone()])

@@ -380,6 +380,55 @@ def test_conv_f64acc(lib, cuda, case, variant, store):
         assert err.max() <= 1e-12 * max(np.abs(ref).max(), 1.0), err.max()
 
 
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize('variant', ['plain', 'relu_residual', 'prologue'])
+def test_conv_f32m(lib, cuda, case, variant):
+    """The fp32-matrix-core kernel of the F32M mode (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation in ascending
+    k) on every conv shape, against fp64 on the same fp32 operands: what is left is fp32 accumulation, <= sqrt(K) ulps of the
+    layer maximum (bar 2e-5 relative: K <= 4608)."""
+    name, n, h_in, c_in, c_out, k, stride, dil, pad, h_out = case
+    if variant == 'prologue' and (k != 1 or pad > 0):
+        pytest.skip('prologue is defined for un-padded 1x1 convs only')
+    rng = np.random.default_rng(zlib.crc32(f'{name}/{variant}/32m'.encode()))
+    x, w, b = _mk(rng, n, h_in, c_in, c_out, k)
+    pro = res = None
+    if variant == 'prologue':
+        pro = (rng.uniform(0.5, 1.5, c_in).astype(np.float32), (rng.standard_normal(c_in) * 0.2).astype(np.float32))
+    if variant == 'relu_residual':
+        res = rng.standard_normal((n, h_out, h_out, c_out)).astype(np.float32)
+    d = H.conv_desc(n, h_in, c_in, h_out, c_out, k, stride, dil, pad, prologue=pro is not None, relu=variant == 'relu_residual',
+                    residual=res is not None, res_h=h_out, out_dtype=_lib.METRO_F32, in_dtype=_lib.METRO_F32)
+    t = [_dev(x, cuda, np.float32), _dev(w, cuda, np.float32), _dev(b, cuda, np.float32)]
+    ts = _dev(pro[0], cuda, np.float32) if pro else None
+    tsh = _dev(pro[1], cuda, np.float32) if pro else None
+    tr = _dev(res, cuda, np.float32) if res is not None else None
+    out = torch.full((n, h_out, h_out, c_out), float('nan'), dtype=torch.float32, device=cuda)
+    check(lib.metro_conv_f32m(C.byref(d), H.ptr(t[0]), H.ptr(t[1]), H.ptr(t[2]), H.ptr(ts), H.ptr(tsh), H.ptr(tr), H.ptr(out), None),
+          'metro_conv_f32m')
+    torch.cuda.synchronize()
+    got = out.cpu().double().numpy()
+    ref = H.ref_conv_nhwc(x, w, b, stride, dil, pad, h_out, pro=pro, relu=variant == 'relu_residual', res=res).numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def test_conv_f32m_stem_3ch(lib, cuda):
+    """7x7/2 stem on the raw 3-channel image with TF explicit pad 3 (resnet_utils.py:125-135), fp32 matrix cores."""
+    from oracle.forward import conv2d_same
+    rng = np.random.default_rng(17)
+    x = rng.random((2, 64, 64, 3)).astype(np.float32)
+    w_hwio = (rng.standard_normal((7, 7, 3, 16)) * 0.1).astype(np.float32)
+    b = (rng.standard_normal(16) * 0.01).astype(np.float32)
+    d = H.conv_desc(2, 64, 3, 32, 16, 7, stride=2, pad=3, out_dtype=_lib.METRO_F32, in_dtype=_lib.METRO_F32)
+    t = [_dev(x, cuda, np.float32), _dev(w_hwio.transpose(3, 0, 1, 2), cuda, np.float32), _dev(b, cuda, np.float32)]
+    out = torch.full((2, 32, 32, 16), float('nan'), dtype=torch.float32, device=cuda)
+    check(lib.metro_conv_f32m(C.byref(d), H.ptr(t[0]), H.ptr(t[1]), H.ptr(t[2]), None, None, None, H.ptr(out), None), 'metro_conv_f32m')
+    torch.cuda.synchronize()
+    ref = conv2d_same(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(w_hwio).double().permute(3, 2, 0, 1), 2, 1,
+                      False).permute(0, 2, 3, 1).numpy() + b
+    assert np.abs(out.cpu().double().numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
 def test_conv_f64acc_stem_3ch(lib, cuda):
     """7x7/2 stem on the raw 3-channel image with TF explicit pad 3 (resnet_utils.py:125-135)."""
     from oracle.forward import conv2d_same

@@ -79,6 +79,9 @@ def test_every_layer_names_its_kernel_without_a_gpu():
     e64 = Engine(ModelSpec(50, 16, 'h36m'), None, 'f64', max_batch=2)
     k64 = e64.layer_kernels(2)
     assert k64[0].startswith('conv_igemm_f64acc<') and k64[-1] == 'softargmax_partial<acc64,logits64> & softargmax_finalize<acc64>'
+    k32 = Engine(ModelSpec(50, 16, 'h36m'), None, 'f32m', max_batch=2).layer_kernels(2)
+    assert k32[0] == 'conv_igemm_f32<64x128,bk32>' and k32[3].startswith('conv_igemm_f32<') and ',v4' in k32[3]
+    assert k32[-1] == 'softargmax_partial<acc64,logits32> & softargmax_finalize<acc64>'
 
 
 def test_head_partials_slot_covers_large_heat_maps():
