@@ -120,7 +120,7 @@ def main(argv=None):
     parser.add_argument('--model-path', type=str, required=True)
     parser.add_argument('--image', type=str, default=None,
                         help='.npy file with a [256,256,3] float image in [0,1]; default: seeded noise')
-    parser.add_argument('--precision', type=str, default=None, choices=['f16', 'f32', 'f64'])
+    parser.add_argument('--precision', type=str, default=None, choices=['f16', 'f32', 'f32m', 'f64'])
     parser.add_argument('--plot', type=str, default=None, help='write the stick-figure plot to this file')
     opts = parser.parse_args(argv)
     if opts.image:
