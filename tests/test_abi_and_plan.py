@@ -214,3 +214,11 @@ def test_model_file_roundtrip(tmp_path):
     np.savez(str(tmp_path / 'junk.npz'), a=np.zeros(3))
     with pytest.raises(ValueError):
         load_model(str(tmp_path / 'junk.npz'))
+
+
+def test_estimate_pose_plans_by_batch_bucket():
+    """The drop-in call takes any N (reference placeholder [None,256,256,3], main.py:109-111): engines are planned per bucket so
+    that up to 256 crops go through ONE metro_forward (kernel dispatch depends on the batch), more in chunks of 256."""
+    from metro_pose3d_amd import inference as INF
+    assert [INF.batch_bucket(n) for n in (1, 8, 9, 64, 65, 256, 257, 5000)] == [8, 8, 64, 64, 256, 256, 256, 256]
+    assert INF.BATCH_BUCKETS[-1] == 256 and INF.MAX_CACHED_ENGINES >= len(INF.BATCH_BUCKETS)
