@@ -100,8 +100,7 @@ struct Lay {
 };
 template <int K, int WM, bool RES, int MODE2, bool PSC = false, int CB = 256>
 constexpr int lds_bytes() {
-    return Lay<K, WM, CB>::RES_OFF + (RES ? 2 * Lay<K, WM, CB>::RES_BYTES : PSC ? 2 * Lay<K, WM, CB>::X_BYTES : 0) +
-           (MODE2 == 2 && CB == 256 ? 64 * 256 * 2 : 0);
+    return Lay<K, WM, CB>::RES_OFF + (RES ? 2 * Lay<K, WM, CB>::RES_BYTES : PSC ? 2 * Lay<K, WM, CB>::X_BYTES : 0);
 }
 }  // namespace pw
 
@@ -138,7 +137,6 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     typedef __attribute__((address_space(3))) void lds_void_t;
     const unsigned smem_base = (unsigned)(size_t)(lds_void_t*)smem;
     constexpr int XS_OFF = RES_OFF;                          // PSC: two buffers of the unit-input tile where the shortcut rows would be
-    constexpr int W2_OFF = RES_OFF + (RES ? 2 * RES_BYTES : PSC ? 2 * X_BYTES : 0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -201,25 +199,19 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     // row-wise pass: this thread always owns 16-byte chunk `ch` of a row
     const int ch = tid & (CPR - 1);
     half8_t sc2 = {}, sh2 = {};
-    half8_t w2r[CB == 512 ? 16 : 1];                         // CB = 512: W1' rows 16 wave .. +15, all 512 k, as 16x16x32 A fragments
-    if constexpr (MODE2 == 2 && CB == 512) {
+    // MODE2 = 2: W2 [C2][CB] (the next unit's conv1) in registers as 16x16x32 A fragments: wave w owns output rows 16 (w % RG) ..
+    // + 15 over the whole K = CB, for the pixels of its pixel group w / RG (round 3: the 64 -> 256 kernels ran this GEMM on four
+    // of their eight waves from an LDS image of W2)
+    constexpr int RG = C2 / 16;                              // row groups: 4 (CB 256) or 8 (CB 512)
+    constexpr int NTW = TN / 16 / (NW / RG);                 // 16-pixel tiles per wave: 2
+    constexpr int KS2 = CB / 32;                             // k steps of 32
+    half8_t w2r[MODE2 == 2 ? KS2 : 1];
+    if constexpr (MODE2 == 2) {
         sc2 = *reinterpret_cast<const half8_t*>(a.scale2 + ch * 8);
         sh2 = *reinterpret_cast<const half8_t*>(a.shift2 + ch * 8);
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
-            w2r[ks] = *reinterpret_cast<const half8_t*>(a.w2 + (size_t)(wave * 16 + (lane & 15)) * 512 + ks * 32 + (lane >> 4) * 8);
-    }
-    if constexpr (MODE2 == 2 && CB == 256) {
-        sc2 = *reinterpret_cast<const half8_t*>(a.scale2 + ch * 8);
-        sh2 = *reinterpret_cast<const half8_t*>(a.shift2 + ch * 8);
-        // W2 [64][256] as 4 swizzled images of 64 rows x 64 k (one per 64-channel slice of K)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int vrow = (i * NW + wave) * 8 + (lane >> 3);
-            const int kc = vrow >> 6, r = vrow & 63;
-            const half_t* src = a.w2 + (size_t)r * 256 + kc * 64 + (((lane & 7) ^ pw_swz(r)) * 8);
-            pw_dma16(src, __builtin_amdgcn_readfirstlane(smem_base + W2_OFF + (i * NW + wave) * 1024));
-        }
+        for (int ks = 0; ks < KS2; ++ks)
+            w2r[ks] = *reinterpret_cast<const half8_t*>(a.w2 + (size_t)((wave % RG) * 16 + (lane & 15)) * CB + ks * 32 + (lane >> 4) * 8);
     }
 
     // ---- per-lane DMA coordinates ------------------------------------------------------------
@@ -265,9 +257,9 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
 
     issue_tile(t, 0);
     // stores of one tile per wave (all younger than the next tile's loads): RI row-wise (+4 second-output)
-    // second-output stores: CB 256: four 8-byte stores by waves 0-3; CB 512: two by every wave
-    constexpr int S2 = CB == 512 ? 2 : 4;
-    const bool two = MODE2 != 0 && (CB == 512 || wave < 4);
+    // second-output stores per tile: MODE2 = 1 four 8-byte stores by waves 0-3; MODE2 = 2 NTW by every wave
+    constexpr int S2 = MODE2 == 2 ? NTW : 4;
+    const bool two = MODE2 == 2 || (MODE2 == 1 && wave < 4);
     bool prev_full = false;
     for (int it = 0;; ++it, t += G) {
         const int buf = it & 1;
@@ -380,58 +372,32 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
                 *reinterpret_cast<half8_t*>(ol + prow * OUT_ROW + ch * 16) = p;
             }
         }
-        if constexpr (MODE2 == 2 && CB == 512) {
+        if constexpr (MODE2 == 2) {
             pw_barrier();
-            // ---- GEMM 2: [128 x 512] x [512 x 32 pixels] from the tile: wave w = output rows 16 w .. 16 w + 15, two 16-pixel tiles,
-            //      16 k steps of 32 (v_mfma_f32_16x16x32_f16: A[i][k] lane (i = lane & 15, k group = lane >> 4), B likewise by pixel)
-            floatx4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-            const char* bl = ol + (lane & 15) * OUT_ROW + (lane >> 4) * 16;
+            // ---- GEMM 2: [C2 x CB] x [CB x TN pixels] from the tile: v_mfma_f32_16x16x32_f16, A[i][k] lane (i = lane & 15, k group =
+            //      lane >> 4), B likewise by pixel, D[i][j] lane (j = lane & 15 -> pixel, rows 4 (lane >> 4) .. + 3)
+            floatx4 dacc[NTW];
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const half8_t b0 = *reinterpret_cast<const half8_t*>(bl + ks * 64);
-                const half8_t b1 = *reinterpret_cast<const half8_t*>(bl + 16 * OUT_ROW + ks * 64);
-                d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2r[ks], b0, d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2r[ks], b1, d1, 0, 0, 0);
+            for (int j = 0; j < NTW; ++j) dacc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            const int px0 = (wave / RG) * (NTW * 16);
+            const char* bl = ol + (px0 + (lane & 15)) * OUT_ROW + (lane >> 4) * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const half8_t bj = *reinterpret_cast<const half8_t*>(bl + j * 16 * OUT_ROW + ks * 64);
+                    dacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2r[ks], bj, dacc[j], 0, 0, 0);
+                }
             }
-            // D[i][j]: lane (j = lane & 15 -> pixel, i group = lane >> 4 -> rows 4 (lane >> 4) .. + 3)
-            const int co = wave * 16 + (lane >> 4) * 4;
+            const int co = (wave % RG) * 16 + (lane >> 4) * 4;
             const floatx4 bv = *reinterpret_cast<const floatx4*>(bias2_l + co);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int m = m0 + j * 16 + (lane & 15);
-                const floatx4 dv = j == 0 ? d0 : d1;
+            for (int j = 0; j < NTW; ++j) {
+                const int m = m0 + px0 + j * 16 + (lane & 15);
                 half4_t hv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = (half_t)fmaxf(dv[e] + bv[e], 0.f);
+                for (int e = 0; e < 4; ++e) hv[e] = (half_t)fmaxf(dacc[j][e] + bv[e], 0.f);
                 if (m < a.m_total) *reinterpret_cast<half4_t*>(a.out2 + (size_t)m * C2 + co) = hv;
-            }
-        }
-        if constexpr (MODE2 == 2 && CB == 256) {
-            pw_barrier();
-            // ---- GEMM 2: [64 x 256] x [256 x 64 pixels] from the tile (waves 0..3, one 32x32 tile each)
-            if (wave < 4) {
-                const int arow = wm * 32 + frag_row;
-                const char* w2l = smem + W2_OFF + arow * 128;
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    const int k0 = ks * 16 + frag_half * 8;
-                    const half8_t af = *reinterpret_cast<const half8_t*>(
-                        w2l + (ks >> 2) * 8192 + ((((ks & 3) * 2 + frag_half) ^ pw_swz(arow)) << 4));
-                    const half8_t bf = *reinterpret_cast<const half8_t*>(ol + brow * OUT_ROW + k0 * 2);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc2, 0, 0, 0);
-                }
-                const int m = m0 + brow;
-                if (m < a.m_total) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int co = wm * 32 + 8 * q + 4 * frag_half;
-                        const floatx4 bv = *reinterpret_cast<const floatx4*>(bias2_l + co);
-                        half4_t hv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hv[e] = (half_t)fmaxf(acc2[4 * q + e] + bv[e], 0.f);
-                        *reinterpret_cast<half4_t*>(a.out2 + (size_t)m * 64 + co) = hv;
-                    }
-                }
             }
         }
         if (t + G >= a.n_tiles) break;

@@ -320,6 +320,34 @@ __global__ __launch_bounds__(256) void softargmax_finalize_kernel(const AccT* __
     const int img = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nj = a.n_joints_head;
+    if (slabs <= 16) {
+        // few records per joint (stride-16 / 32 heads: 4 or 1): one thread per joint walks them -- the shuffle folds of the wave
+        // form cost more than they save here (8.3 vs 4.6 us at batch 64)
+        const int j = threadIdx.x;
+        if (j < nj) {
+            AccT M = (AccT)-INFINITY;
+            for (int sl = 0; sl < slabs; ++sl) {
+                const AccT mv = partials[(((size_t)img * slabs + sl) * nj + j) * 5];
+                M = mv > M ? mv : M;
+            }
+            AccT S = 0, SX = 0, SY = 0, SZ = 0;
+            for (int sl = 0; sl < slabs; ++sl) {
+                const AccT* r = partials + (((size_t)img * slabs + sl) * nj + j) * 5;
+                if (r[1] > 0) {
+                    const AccT f = acc_exp<AccT>(r[0] - M);
+                    S += r[1] * f; SX += r[2] * f; SY += r[3] * f; SZ += r[4] * f;
+                }
+            }
+            const AccT x01 = SX / S, y01 = SY / S, z01 = SZ / S;
+            if (coords01 != nullptr) {
+                float* c = coords01 + ((size_t)img * nj + j) * 3;
+                c[0] = (float)x01; c[1] = (float)y01; c[2] = (float)z01;
+            }
+            mm[j][0] = (x01 * (AccT)a.lrc + (AccT)a.half_off) * (AccT)a.box_size_mm / (AccT)a.proc_side;
+            mm[j][1] = (y01 * (AccT)a.lrc + (AccT)a.half_off) * (AccT)a.box_size_mm / (AccT)a.proc_side;
+            mm[j][2] = z01 * (AccT)a.box_size_mm;
+        }
+    } else
     for (int j = wave; j < nj; j += 4) {
         AccT M = (AccT)-INFINITY;
         for (int sl = lane; sl < slabs; sl += 64) {
