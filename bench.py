@@ -27,8 +27,11 @@ One JSON line on stdout from rank 0, with
                   quotes its roofline target on: crops/s, ms/step and its own roofline object;
   c3_shard, c4_shard, c5_shard -- (N = 1) one GPU's shard of BASELINE.json configs[2..4] (RN50-s16-J19
                   batch 512/8, RN101-s8-J19 batch 256/8, RN50-s4-J17 batch 128/8), each with its roofline;
-  boundary     -- (N = 1) 256 crops through `estimate_pose` itself (the drop-in call of reference
-                  inference.py:31-43, model file -> poses), Python overhead included.
+  boundary     -- 256 crops through `estimate_pose` itself (the drop-in call of reference inference.py:31-43, model file ->
+                  poses), Python overhead included; N > 1: the same call on every rank with the global batch -- sharded by
+                  image inside the call, one RCCL all-gather of the poses;
+  softargmax_hbm -- (N = 1) the stand-alone soft-argmax on resident fp32 logits at the configs[4] and configs[1] volumes with
+                  an HBM roofline object (`bound: "hbm"`), the second number SURVEY 8(d) asks for.
 """
 from __future__ import annotations
 
@@ -295,12 +298,74 @@ def boundary_leg(device, dist, spec, params, batch, steps, warmup):
             poses, _, _ = INF.estimate_pose(img, path)
         el, gms, per = timed_steps(lambda: INF.estimate_pose(img, path), steps, device, 1, dist)
         ok = bool(torch.isfinite(poses).all())
-        INF._ENGINES.clear()
+        INF.clear_cache()
     return {'call': f'metro_pose3d_amd.inference.estimate_pose(images[{batch},256,256,3] on the GPU, model_path) -> poses on the GPU',
             'value': round(batch * steps / el, 2), 'unit': 'crops/s', 'steps': steps, 'ms_per_call': round(el * 1e3 / steps, 4),
             'gpu_ms_per_call_median': round(float(np.median(per)), 4), 'finite': ok,
             'note': 'one metro_forward(n = 256) per call (the engine is planned for the batch the call is given); includes the '
-                    'Python argument checks, output allocation and the names/edges arrays of every call'}
+                    'Python argument checks, output allocation, the names/edges arrays and the non-finite screen of every call '
+                    '(metro_forward_status: one stream synchronisation, like the reference\'s blocking sess.run)'}
+
+
+def sharded_boundary_leg(device, dist, spec, params, per_gpu, world, rank, steps, warmup):
+    """N > 1: the SAME drop-in call on every rank with the same global batch -- estimate_pose shards it by image, forwards the
+    rank's shard and all-gathers the poses (RCCL under backend nccl).  Max over ranks, like the main timed region."""
+    import tempfile
+    from metro_pose3d_amd import save_model, synth
+    from metro_pose3d_amd import inference as INF
+    n = per_gpu * world
+    td = tempfile.mkdtemp(prefix=f'metro_bench_r{rank}_')
+    path = os.path.join(td, 'model.npz')
+    save_model(path, spec, params)
+    img = torch.cat([torch.from_numpy(synth.make_images(per_gpu, spec.proc_side, seed=1234 + r)) for r in range(world)]).to(device)
+    for _ in range(warmup):
+        poses, _, _ = INF.estimate_pose(img, path)
+    el, gms, per = timed_steps(lambda: INF.estimate_pose(img, path), steps, device, world, dist)
+    t = torch.tensor([el], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    ok = bool(torch.isfinite(poses).all()) and tuple(poses.shape) == (n, spec.skeleton.n_out, 3)
+    INF.clear_cache()
+    os.remove(path)
+    os.rmdir(td)
+    return {'call': f'estimate_pose(images[{n},256,256,3], model_path) on each of {world} ranks -> all {n} poses on every rank',
+            'value': round(n * steps / el, 2), 'unit': 'crops/s', 'steps': steps, 'ms_per_call': round(el * 1e3 / steps, 4),
+            'crops_per_rank': per_gpu, 'complete_and_finite': ok,
+            'note': 'each rank forwards dist.shard_range(N, rank, world) and joins ONE all-gather of [N/G, Jout, 3] fp32; '
+                    'not overlapped with the next call (the call returns the gathered poses), non-finite screen on'}
+
+
+def softargmax_hbm_leg(device, dist, stride, dataset, crops, steps, warmup, what):
+    """The HBM-bound piece of the path on its own: stand-alone metro_softargmax on resident fp32 logits
+    [n, S, S, 8J] -> poses, i.e. tfu.softmax + decode_heatmap + heatmap_to_metric + root_relative + gather (reference
+    volumetric.py:227-235, tfu.py:466-499).  Algorithmic bytes: 4*8*J*S*S read + 12*Jout written per crop."""
+    import ctypes as C
+    from metro_pose3d_amd import ModelSpec, _lib
+    spec = ModelSpec(50, stride, dataset)
+    lib = _lib.load()
+    s, c, jo = spec.heatmap_side, spec.n_head_channels, spec.skeleton.n_out
+    g = torch.Generator(device='cpu').manual_seed(5)
+    logits = (torch.randn((crops, s, s, c), generator=g) * 4.0).to(device)
+    scratch = torch.empty(lib.metro_softargmax_scratch_bytes(crops, s, spec.skeleton.n_head), dtype=torch.uint8, device=device)
+    out = torch.empty((crops, jo, 3), dtype=torch.float32, device=device)
+    cs = spec.to_c(0)
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def step():
+        _lib.check(lib.metro_softargmax(C.c_void_p(logits.data_ptr()), crops, C.byref(cs), 0, C.c_void_p(scratch.data_ptr()),
+                                        C.c_void_p(out.data_ptr()), C.c_void_p(stream)), 'metro_softargmax')
+    for _ in range(warmup):
+        step()
+    el, gms, per = timed_steps(step, steps, device, 1, dist)
+    us = float(np.median(per)) * 1e3
+    algo = crops * (4 * c * s * s + 12 * jo)
+    gbs = algo / (us * 1e-6) / 1e9
+    return {'workload': f'stand-alone soft-argmax, {what}: fp32 logits [{crops},{s},{s},{c}] = {crops * 4 * c * s * s / 1e6:.1f} MB -> poses [{crops},{jo},3]',
+            'value': round(crops / (us * 1e-6), 1), 'unit': 'crops/s', 'us_per_call_median': round(us, 2), 'steps': steps,
+            'finite': bool(torch.isfinite(out).all()),
+            'roofline': {'bound': 'hbm', 'kernel': 'softargmax_partial<acc32,logits32> + softargmax_finalize<acc32> (both launches timed together)',
+                         'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None,
+                         'algorithmic_bytes_per_call': int(algo)}}
 
 
 def main():
@@ -483,6 +548,14 @@ def main():
             out['c4_shard'] = side_workload(device, dist, 101, 8, 'many19', 32, 10, 3, 'configs[3]: batch 256 sharded over 8 GPUs')
             out['c5_shard'] = side_workload(device, dist, 50, 4, 'h36m', 16, 10, 3, 'configs[4]: batch 128 sharded over 8 GPUs')
             out['boundary'] = boundary_leg(device, dist, spec, params, 256, 10, 2)
+            # the HBM-bound number SURVEY 8(d) asks for next to the MFMA one: the soft-argmax on its own
+            out['softargmax_hbm'] = {'c5_volume': softargmax_hbm_leg(device, dist, 4, 'h36m', 128, 20, 3, 'configs[4] volume (S = 64, J = 17), 128 crops'),
+                                     'c2_volume': softargmax_hbm_leg(device, dist, 16, 'h36m', 64, 50, 5, 'configs[1] volume (S = 16, J = 17), 64 crops'),
+                                     'c2_volume_b2048': softargmax_hbm_leg(device, dist, 16, 'h36m', 2048, 20, 3, 'configs[1] volume, 2048 crops (same bytes as the C5 case)')}
+    if world > 1 and not args.no_extras and args.precision == 'f16':
+        rec = sharded_boundary_leg(device, dist, spec, params, b, world, rank, 10, 2)      # collective: every rank takes part
+        if rank == 0:
+            out['boundary'] = rec
     if rank == 0:
         if world == 1 and args.cpu_seconds > 0:
             out['cpu_baseline'] = cpu_baseline(spec, params, args.cpu_seconds, args.cpu_crops)

@@ -25,14 +25,15 @@
 extern "C" {
 #endif
 
-#define METRO_ABI_VERSION 5
+#define METRO_ABI_VERSION 6
 
 typedef enum MetroStatus {
     METRO_OK = 0,
     METRO_ERR_INVALID_ARG = -1,
     METRO_ERR_UNSUPPORTED = -2,
     METRO_ERR_HIP = -3,
-    METRO_ERR_STATE = -4
+    METRO_ERR_STATE = -4,
+    METRO_ERR_NONFINITE = -5   /* metro_forward_status: non-finite activations reached the soft-argmax */
 } MetroStatus;
 
 /* Arithmetic mode of a plan.  Images are always fp32 in, poses fp32 out.
@@ -159,6 +160,13 @@ int  metro_forward(MetroPlan* plan, const float* d_images_nhwc, int32_t n, float
  * n <= max_batch_for_graphs are captured once per (n, buffers, stream) into a hipGraph and replayed.
  * 0 (default) = always plain launches.  The capture happens on the second call with a given key. */
 int  metro_plan_set_graph_max_batch(MetroPlan* plan, int32_t max_batch_for_graphs);
+/* Non-finite screen of the LAST metro_forward(n) on this workspace.  The reference keeps fp32 variables under fp16 compute
+ * (reference src/tfu.py:426-440) and TensorFlow hands NaN poses back silently when an activation overflows fp16 (65 504); here
+ * the finalize launch writes one int32 per image into the workspace (1 = a soft-argmax record, maximum or normaliser of that
+ * image was not finite; a NaN record is never silently dropped) and this call copies the n words to the host -- it
+ * SYNCHRONISES the stream, the only entry point of the path that does.  *n_nonfinite_out = number of flagged images; returns
+ * METRO_ERR_NONFINITE (metro_last_error() names the remedy: precision f32m / f64) when it is not zero. */
+int  metro_forward_status(const MetroPlan* plan, const void* d_workspace, int32_t n, void* stream, int32_t* n_nonfinite_out);
 /* Same, stopping after layer `last_layer` (inclusive) so tests can read that layer's output at
  * MetroLayerInfo.out_offset in the workspace.  d_poses_out may be NULL if the finalize layer
  * is not reached. */
@@ -237,7 +245,9 @@ int  metro_conv_f16_gemm8p(const MetroConvDesc* d, const void* d_in, const void*
                            const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
                            int32_t split, void* d_out2, void* stream);
 /* The same contract and shapes on the FOUR-wave form of that GEMM (conv_gemm4w.hip: 128 x 128 wave tiles, register-staged
- * operands, one barrier per K tile), which metro_forward picks from 128 crops per call on.  Bit-identical to
+ * operands, one barrier per K tile), which metro_forward picks for EVERY pre-activated layer the 8-phase kernel is eligible for
+ * (conv1, projection shortcut, shortcut+conv1 pair: >= 256 tiles of 256 x 256, K >= 1024 or >= 1024 tiles), whatever the batch;
+ * bare GEMMs stay on the 8-phase kernel.  Bit-identical to
  * metro_conv_f16_gemm8p (same K order, one fp32 accumulator per output). */
 int  metro_conv_f16_gemm4w(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                            const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
@@ -270,8 +280,10 @@ int  metro_prep_input_f16(const float* d_images, int32_t n, int32_t side, void* 
 /* Crop pre-processing, the step before the path: n crops of one uint8
  * HWC RGB frame [h, w, 3] (row_stride bytes per row), crop i sampled through the 3x3 homography
  * d_homographies[i] (row-major fp32, maps OUTPUT pixel (x, y, 1) to SOURCE pixel coordinates) with
- * bilinear interpolation and constant-0 border, then /255 and clip -- reference
- * src/cameralib.py:406-429 (reproject_image_fast -> cv2.remap) + src/improc.py:56-61 (normalize01).
+ * OpenCV's 8-bit remap rule (coordinates rounded to 1/32 px, 15-bit weights, result rounded to uint8, constant-0 border: the
+ * reference warps the uint8 frame), then /255 and clip -- reference src/cameralib.py:406-429 (reproject_image_fast ->
+ * cv2.remap INTER_LINEAR) + src/improc.py:56-61 (normalize01).  Every output value is k/255 for the byte k cv2 produces.
+ * h, w <= 32767 (OpenCV holds the integer coordinate in a short).
  * d_out: fp32 NHWC [n, side, side, 3], exactly the input contract of metro_forward. */
 int  metro_warp_crop_u8(const uint8_t* d_image, int32_t h, int32_t w, int32_t row_stride,
                         const float* d_homographies, int32_t n, int32_t side, float* d_out, void* stream);

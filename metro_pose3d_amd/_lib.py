@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('METRO_HIP_LIB') or os.path.join(HERE, 'libmetro_hip.so')   # override: timing experiments
 
 METRO_MAX_JOINTS = 64
-ABI_VERSION = 5          # include/metro_hip.h METRO_ABI_VERSION
+ABI_VERSION = 6          # include/metro_hip.h METRO_ABI_VERSION
 METRO_PREC_F16, METRO_PREC_F32, METRO_PREC_F64, METRO_PREC_F32M = 0, 1, 2, 3
 METRO_F16, METRO_F32, METRO_F64 = 0, 1, 2
 PARAM_CONV_W, PARAM_BIAS, PARAM_PRO_SCALE, PARAM_PRO_SHIFT = 0, 1, 2, 3
@@ -75,6 +75,7 @@ SIGNATURES = {
     'metro_last_kernel_id': (C.c_char_p, []),
     'metro_plan_set_graph_max_batch': (C.c_int, [_P, C.c_int32]),
     'metro_forward': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
+    'metro_forward_status': (C.c_int, [_P, _P, C.c_int32, _P, C.POINTER(C.c_int32)]),
     'metro_forward_upto': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32]),
     'metro_forward_timed': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_float)]),
     'metro_conv_f16': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -114,6 +115,10 @@ class MetroError(RuntimeError):
     pass
 
 
+class NonFiniteError(MetroError):
+    """metro_forward_status: activations overflowed the arithmetic mode (fp16 storage tops out at 65 504)."""
+
+
 def load() -> C.CDLL:
     """Loads libmetro_hip.so.  Raises (never falls back) when it is missing."""
     global _lib
@@ -143,4 +148,6 @@ def check(status: int, what: str = '') -> None:
     msg = load().metro_last_error().decode(errors='replace')
     if status == -1:
         raise ValueError(f'{what}: {msg}')
+    if status == -5:
+        raise NonFiniteError(f'{what}: {msg}')
     raise MetroError(f'{what}: status {status}: {msg}')

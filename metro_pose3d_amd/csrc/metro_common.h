@@ -50,7 +50,7 @@ inline int tuning_knob(const char* name, int dflt) {
 // launch.  Off (the default) it is one thread-local load; mode 1 appends the id to a thread-local string
 // (metro_last_kernel_id); mode 2 is a DRY RUN: the id is recorded and the launcher returns METRO_OK without touching
 // the device (metro_plan_layer_kernel, and the coverage test in tests/test_kernel_coverage.py, work without a GPU).
-struct KernelNotes { int mode; char ids[256]; };
+struct KernelNotes { int mode; char ids[1024]; };   // a string that did not fit ends in " ..." (tests assert against it)
 KernelNotes& kernel_notes();
 bool note_kernel(const char* fmt, ...) __attribute__((format(printf, 1, 2)));   // true = dry run: skip the launch
 
@@ -127,6 +127,10 @@ inline int ensure_dyn_lds_and_grid_cap(const void* kern, int threads, int bytes,
 }
 
 inline int launch_status(const char* what) {
+    if (kernel_notes().mode == 2) {     // a leaf launcher that did not call note_kernel() before touching the device
+        set_error("internal: %s was launched during a dry run (note_kernel must come first)", what);
+        return METRO_ERR_STATE;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("launch of %s failed: %s", what, hipGetErrorString(e));
@@ -272,10 +276,11 @@ struct SoftArgmaxArgs {
 int softargmax_slabs(int n, int side);
 int64_t softargmax_scratch_bytes(int n, int side, int n_joints_head);
 int launch_softargmax(const void* logits, const SoftArgmaxArgs& a, int precise, void* partials,
-                      float* poses_out, hipStream_t stream, float* coords01_out = nullptr);
+                      float* poses_out, hipStream_t stream, float* coords01_out = nullptr, int32_t* status = nullptr);
+// `status` (optional, int32 [n]): 1 where an image's soft-argmax statistics were not finite (fp16 overflow upstream), else 0
 // finalize only (slabs folded, mm decode, root-relative, permutation) on fp32 partials written by another kernel
 int launch_softargmax_finalize(const float* partials, const SoftArgmaxArgs& a, int slabs, float* poses_out,
-                               hipStream_t stream, float* coords01_out = nullptr);
+                               hipStream_t stream, float* coords01_out = nullptr, int32_t* status = nullptr);
 // the volumetric head in one launch (head_f16.hip): postnorm prologue + logits GEMM + per-joint softmax statistics
 bool head_f16_supported(int c_in, int c_head, int n_joints, int depth, int side);
 int head_f16_slabs(int side);               // records per image the partials slot must hold

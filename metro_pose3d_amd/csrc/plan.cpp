@@ -30,15 +30,21 @@ static thread_local KernelNotes g_notes = {0, ""};
 KernelNotes& kernel_notes() { return g_notes; }
 bool note_kernel(const char* fmt, ...) {
     if (g_notes.mode == 0) return false;
+    // Mode 1 accumulates until metro_kernel_notes() is called again; an id that does not fit the 1 KiB string is replaced by a
+    // trailing " ..." so a truncated string can never pass for an id (a whole metro_forward of ~46 launches does not fit: mode 1
+    // is meant for ONE single-kernel entry-point call at a time).
+    const size_t cap = sizeof(g_notes.ids) - 5;           // room for " ..."
     const size_t used = strlen(g_notes.ids);
-    if (used + 2 < sizeof(g_notes.ids)) {
-        size_t at = used;
-        if (used && used + 4 < sizeof(g_notes.ids)) { memcpy(g_notes.ids + at, " & ", 3); at += 3; }   // several kernels: a & b
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(g_notes.ids + at, sizeof(g_notes.ids) - at, fmt, ap);
-        va_end(ap);
-    }
+    if (used >= 4 && strcmp(g_notes.ids + used - 4, " ...") == 0) return g_notes.mode == 2;
+    char one[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(one, sizeof(one), fmt, ap);
+    va_end(ap);
+    const size_t need = strlen(one) + (used ? 3 : 0);
+    if (used + need > cap) { memcpy(g_notes.ids + used, " ...", 5); return g_notes.mode == 2; }
+    if (used) memcpy(g_notes.ids + used, " & ", 3);       // several kernels: a & b
+    memcpy(g_notes.ids + used + (used ? 3 : 0), one, strlen(one) + 1);
     return g_notes.mode == 2;
 }
 
@@ -75,7 +81,7 @@ using namespace metro;
 namespace {
 
 enum LayerKind { LK_PREP = 0, LK_CONV = 1, LK_POOL = 2, LK_SOFTARGMAX = 3 };
-enum Slot { S_IMAGES = -2, S_NONE = -1, S_PREP = 0, S_STEM, S_X0, S_X1, S_T1, S_T2, S_SC, S_LOGITS, S_PART, S_COUNT };
+enum Slot { S_IMAGES = -2, S_NONE = -1, S_PREP = 0, S_STEM, S_X0, S_X1, S_T1, S_T2, S_SC, S_LOGITS, S_PART, S_STATUS, S_COUNT };
 
 struct Layer {
     MetroLayerInfo info;
@@ -569,6 +575,7 @@ int build_plan(MetroPlan* p) {
             if (head_fused)
                 bytes = std::max(bytes, (int64_t)p->max_batch * head_f16_slabs(hs) * sp.n_joints_head * 5 * 4);
         }
+        if (s == S_STATUS) bytes = (int64_t)p->max_batch * 4;      // int32 per image: the finalize launch's non-finite screen
         off = align_up(off + bytes, 256);
     }
     p->workspace_bytes = off;
@@ -613,14 +620,14 @@ int build_plan(MetroPlan* p) {
 
 // One layer of the plan at batch n.  `dump` (metro_forward_upto stopping at this layer): launches whose intermediate tensors live on
 // chip also write them out -- the fp32 logits of the one-launch head, conv1's output of a conv1+conv2 launch.
-int launch_layer(MetroPlan* p, int li, const float* images, int n, float* poses, char* ws, hipStream_t stream, bool dump) {
-    Layer& L = p->layers[li];
+int launch_layer(const MetroPlan* p, const char* d_params, int li, const float* images, int n, float* poses, char* ws, hipStream_t stream, bool dump) {
+    const Layer& L = p->layers[li];
     auto slot_ptr = [&](int slot) -> void* {
         if (slot == S_IMAGES) return const_cast<float*>(images);
         if (slot < 0) return nullptr;
         return ws + p->slot_offset[slot];
     };
-    auto prm = [&](int idx) -> const void* { return idx < 0 ? nullptr : p->d_params + p->params[idx].offset; };
+    auto prm = [&](int idx) -> const void* { return idx < 0 ? nullptr : d_params + p->params[idx].offset; };
     switch (L.kind) {
         case LK_PREP:
             return launch_prep_input_f16(images, n, p->spec.proc_side, slot_ptr(L.out_slot), stream);
@@ -684,9 +691,11 @@ int launch_layer(MetroPlan* p, int li, const float* images, int n, float* poses,
             if (poses == nullptr) { set_error("metro_forward: poses_out is NULL"); return METRO_ERR_INVALID_ARG; }
             const SoftArgmaxArgs a = make_softargmax_args(p->spec, n);
             if (L.head_fused)
-                return launch_softargmax_finalize(static_cast<const float*>(slot_ptr(S_PART)), a, head_f16_records(n, a.side), poses, stream);
+                return launch_softargmax_finalize(static_cast<const float*>(slot_ptr(S_PART)), a, head_f16_records(n, a.side), poses, stream, nullptr,
+                                                  static_cast<int32_t*>(slot_ptr(S_STATUS)));
             // precise: 0 fp32 / fp32, 1 fp32 logits + fp64 accumulators (F32 and F32M modes), 2 fp64 / fp64
-            return launch_softargmax(slot_ptr(L.in_slot), a, p->spec.precision == METRO_PREC_F32M ? 1 : p->spec.precision, slot_ptr(S_PART), poses, stream);
+            return launch_softargmax(slot_ptr(L.in_slot), a, p->spec.precision == METRO_PREC_F32M ? 1 : p->spec.precision, slot_ptr(S_PART), poses, stream,
+                                     nullptr, static_cast<int32_t*>(slot_ptr(S_STATUS)));
         }
     }
     set_error("internal: layer %d has unknown kind %d", li, L.kind);
@@ -711,7 +720,7 @@ int run_layers(MetroPlan* p, const float* images, int n, float* poses, void* ws_
     int st = METRO_OK;
     for (int li = 0; li <= last_layer && st == METRO_OK; ++li) {
         if (ms_out) METRO_HIP_CHECK(hipEventRecord(ev[2 * li], stream));
-        st = launch_layer(p, li, images, n, poses, ws, stream, li == last_layer && li + 1 < nl);
+        st = launch_layer(p, p->d_params, li, images, n, poses, ws, stream, li == last_layer && li + 1 < nl);
         if (ms_out) METRO_HIP_CHECK(hipEventRecord(ev[2 * li + 1], stream));
     }
     if (ms_out) {
@@ -801,14 +810,10 @@ int metro_plan_layer_kernel(const MetroPlan* plan, int32_t index, int32_t n, cha
     KernelNotes& kn = kernel_notes();
     const KernelNotes saved = kn;
     kn.mode = 2; kn.ids[0] = 0;
-    MetroPlan* p = const_cast<MetroPlan*>(plan);
-    const char* saved_params = p->d_params;
-    static const char fake = 0;                       // pointers are never dereferenced in a dry run
-    if (p->d_params == nullptr) p->d_params = &fake;
+    static const char fake = 0;                       // pointers are never dereferenced in a dry run (launch_status asserts it)
     float dummy_poses = 0.f;
-    const int st = launch_layer(p, index, reinterpret_cast<const float*>(&fake), n, &dummy_poses,
+    const int st = launch_layer(plan, &fake, index, reinterpret_cast<const float*>(&fake), n, &dummy_poses,
                                 const_cast<char*>(&fake), nullptr, false);
-    p->d_params = saved_params;
     snprintf(buf, (size_t)buf_len, "%s", kn.ids);
     kn = saved;
     return st;
@@ -874,6 +879,25 @@ int metro_forward(MetroPlan* plan, const float* d_images_nhwc, int32_t n, float*
         if (ei != hipSuccess) { hit->exec = nullptr; set_error("hipGraphInstantiate: %s", hipGetErrorString(ei)); return METRO_ERR_HIP; }
     }
     METRO_HIP_CHECK(hipGraphLaunch(hit->exec, stream));
+    return METRO_OK;
+}
+
+int metro_forward_status(const MetroPlan* plan, const void* d_workspace, int32_t n, void* stream_, int32_t* n_nonfinite_out) {
+    METRO_CHECK_ARG(plan && d_workspace && n_nonfinite_out, "metro_forward_status: NULL argument");
+    METRO_CHECK_ARG(n > 0 && n <= plan->max_batch, "metro_forward_status: batch %d outside [1, %d]", n, plan->max_batch);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    std::vector<int32_t> host((size_t)n);
+    METRO_HIP_CHECK(hipMemcpyAsync(host.data(), static_cast<const char*>(d_workspace) + plan->slot_offset[S_STATUS], (size_t)n * 4,
+                                   hipMemcpyDeviceToHost, stream));
+    METRO_HIP_CHECK(hipStreamSynchronize(stream));
+    int32_t bad = 0;
+    for (int32_t v : host) bad += v != 0;
+    *n_nonfinite_out = bad;
+    if (bad) {
+        set_error("%d of %d crops reached the soft-argmax with non-finite statistics%s", bad, n,
+                  plan->spec.precision == METRO_PREC_F16 ? " (fp16 storage overflows at 65504: run this model with precision f32m or f64)" : "");
+        return METRO_ERR_NONFINITE;
+    }
     return METRO_OK;
 }
 
@@ -1047,6 +1071,7 @@ int metro_warp_crop_u8(const uint8_t* d_image, int32_t h, int32_t w, int32_t row
                        int32_t n, int32_t side, float* d_out, void* stream) {
     METRO_CHECK_ARG(d_image && d_homographies && d_out, "warp_crop_u8: NULL pointer");
     METRO_CHECK_ARG(h > 0 && w > 0 && n > 0 && side > 0 && row_stride >= 3 * w, "warp_crop_u8: bad geometry (h %d w %d stride %d n %d side %d)", h, w, row_stride, n, side);
+    METRO_CHECK_ARG(h <= 32767 && w <= 32767, "warp_crop_u8: frames larger than 32767 pixels a side are outside cv2.remap's short coordinates (h %d w %d)", h, w);
     return launch_warp_crop_u8(d_image, h, w, row_stride, d_homographies, d_out, n, side, static_cast<hipStream_t>(stream));
 }
 

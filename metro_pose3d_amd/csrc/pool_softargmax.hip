@@ -46,15 +46,24 @@ int launch_prep_input_f16(const float* images, int n, int side, void* out, hipSt
 }
 
 // ---------------------------------------------------------------------------------------------
-// Crop pre-processing (the step BEFORE the path): for every output
-// pixel (x, y) of crop i, source coords = H_i * [x, y, 1] (fp32, perspective divide), bilinear
-// sample of the uint8 HWC frame with constant-0 border, then /255 and clip to [-1, 1]:
-// reference src/cameralib.py:406-429 (reproject_image_fast: homography -> cv2.remap INTER_LINEAR,
-// BORDER_CONSTANT 0) followed by src/improc.py:56-61 (normalize01).  OpenCV's remap interpolates in
-// fixed point (coordinates rounded to 1/32 px, 15-bit weights); this kernel interpolates in fp32,
-// so it can differ from cv2 by up to ~1 uint8 LSB (0.004) -- stated in DESIGN.md, not hidden.
+// Crop pre-processing (the step BEFORE the path): for every output pixel (x, y) of crop i, source
+// coords = H_i * [x, y, 1] (fp32, perspective divide), cv2.remap(INTER_LINEAR, BORDER_CONSTANT 0) of the UINT8 HWC frame, then
+// /255 and clip to [-1, 1]: reference src/cameralib.py:406-429 (reproject_image_fast) + src/improc.py:56-61 (normalize01).
+// A byte path, reproduced to the byte (oracle/preprocess.py restates the rule from OpenCV's imgwarp.cpp):
+//   * coordinates as NumPy's float32 matmul evaluates them: fma(h2, 1, fma(h1, y, rn(h0 * x))), IEEE divide;
+//   * OpenCV's fixed point for 8-bit images: s = cvRound(coord * 32) (half to even; NaN / out of int range -> INT_MIN),
+//     integer part saturate_cast<short>(s >> 5), 5-bit fractions ax, ay;
+//   * 15-bit weights 32 (32 - ay)(32 - ax), 32 (32 - ay) ax, 32 ay (32 - ax), 32 ay ax -- OpenCV's table entry for ax = ay = 0 is
+//     (32767, 0, 0, 1) after its sum correction; (32768, 0, 0, 0) gives the same byte for every input since |S11 - S00| < 2^14;
+//   * dst = (sum of in-image taps * weights + 2^14) >> 15 (out-of-image taps are the border value 0), a uint8;
+//   * normalize01: float(dst) / 255 (IEEE divide), clip.
 // One thread per output pixel (3 channels), 12-byte stores.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cv_round_x86(float v) {
+    // cvtss2si: round half to even; NaN and |v| >= 2^31 give the "integer indefinite" INT_MIN
+    return (fabsf(v) < 2147483648.f) ? __float2int_rn(v) : (int)0x80000000;
+}
+
 __global__ __launch_bounds__(256) void warp_crop_u8_kernel(const unsigned char* __restrict__ img, int h, int w,
                                                            int row_stride, const float* __restrict__ homs,
                                                            float* __restrict__ out, int n, int side) {
@@ -66,30 +75,31 @@ __global__ __launch_bounds__(256) void warp_crop_u8_kernel(const unsigned char* 
         const int i = (int)(t / side);
         const float* H = homs + i * 9;
         const float fx = (float)x, fy = (float)y;
-        const float cx = H[0] * fx + H[1] * fy + H[2];
-        const float cy = H[3] * fx + H[4] * fy + H[5];
-        const float cw = H[6] * fx + H[7] * fy + H[8];
-        const float u = cx / cw, v = cy / cw;
-        const float uf = floorf(u), vf = floorf(v);
-        const float a = u - uf, b = v - vf;
-        const int x0 = (int)uf, y0 = (int)vf;
-        float acc[3] = {0.f, 0.f, 0.f};
-        // NaN / huge coordinates fail every bounds test and yield the border value 0
+        const float cx = __fmaf_rn(H[2], 1.f, __fmaf_rn(H[1], fy, __fmul_rn(H[0], fx)));
+        const float cy = __fmaf_rn(H[5], 1.f, __fmaf_rn(H[4], fy, __fmul_rn(H[3], fx)));
+        const float cw = __fmaf_rn(H[8], 1.f, __fmaf_rn(H[7], fy, __fmul_rn(H[6], fx)));
+        const float u = __fdiv_rn(cx, cw), v = __fdiv_rn(cy, cw);
+        const int sx = cv_round_x86(__fmul_rn(u, 32.f)), sy = cv_round_x86(__fmul_rn(v, 32.f));
+        const int ax = sx & 31, ay = sy & 31;
+        int x0 = sx >> 5, y0 = sy >> 5;
+        x0 = x0 < -32768 ? -32768 : (x0 > 32767 ? 32767 : x0);          // saturate_cast<short>
+        y0 = y0 < -32768 ? -32768 : (y0 > 32767 ? 32767 : y0);
+        const int wgt[4] = {32 * (32 - ay) * (32 - ax), 32 * (32 - ay) * ax, 32 * ay * (32 - ax), 32 * ay * ax};
+        int acc[3] = {0, 0, 0};
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const int xx = x0 + dx, yy = y0 + dy;
-                const float wgt = (dx ? a : 1.f - a) * (dy ? b : 1.f - b);
-                if ((unsigned)xx < (unsigned)w && (unsigned)yy < (unsigned)h && u == u && v == v) {
-                    const unsigned char* s = img + (size_t)yy * row_stride + (size_t)xx * 3;
-                    acc[0] += wgt * (float)s[0]; acc[1] += wgt * (float)s[1]; acc[2] += wgt * (float)s[2];
-                }
+        for (int k = 0; k < 4; ++k) {
+            const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+            if ((unsigned)xx < (unsigned)w && (unsigned)yy < (unsigned)h) {
+                const unsigned char* s = img + (size_t)yy * row_stride + (size_t)xx * 3;
+                acc[0] += wgt[k] * (int)s[0]; acc[1] += wgt[k] * (int)s[1]; acc[2] += wgt[k] * (int)s[2];
             }
         }
         float* o = out + p * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = fminf(fmaxf(acc[c] / 255.f, -1.f), 1.f);
+        for (int c = 0; c < 3; ++c) {
+            const int byte = (acc[c] + (1 << 14)) >> 15;                  // <= 255: the weights sum to 2^15
+            o[c] = fminf(fmaxf(__fdiv_rn((float)byte, 255.f), -1.f), 1.f);
+        }
     }
 }
 
@@ -315,8 +325,16 @@ template <typename AccT>
 __global__ __launch_bounds__(256) void softargmax_finalize_kernel(const AccT* __restrict__ partials,
                                                                   float* __restrict__ poses,
                                                                   SoftArgmaxArgs a, int slabs,
-                                                                  float* __restrict__ coords01) {
+                                                                  float* __restrict__ coords01,
+                                                                  int32_t* __restrict__ status) {
     __shared__ AccT mm[METRO_MAX_JOINTS][3];
+    // Non-finite screen (status[img] = 1): a record whose sum is NaN, a non-finite maximum or normaliser.  fp16 storage overflows
+    // at 65 504: an Inf in the residual stream reaches every logit of its pixel (reference tfu.py:426-440 keeps fp32 variables
+    // for the same reason); `r[1] > 0` alone would silently DROP a NaN record and return a finite, wrong pose.
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    bool bad = false;
     const int img = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nj = a.n_joints_head;
@@ -336,8 +354,9 @@ __global__ __launch_bounds__(256) void softargmax_finalize_kernel(const AccT* __
                 if (r[1] > 0) {
                     const AccT f = acc_exp<AccT>(r[0] - M);
                     S += r[1] * f; SX += r[2] * f; SY += r[3] * f; SZ += r[4] * f;
-                }
+                } else bad = true;
             }
+            bad = bad || !(M - M == (AccT)0) || !(S - S == (AccT)0) || !(SX - SX == (AccT)0) || !(SY - SY == (AccT)0) || !(SZ - SZ == (AccT)0);
             const AccT x01 = SX / S, y01 = SY / S, z01 = SZ / S;
             if (coords01 != nullptr) {
                 float* c = coords01 + ((size_t)img * nj + j) * 3;
@@ -365,9 +384,10 @@ __global__ __launch_bounds__(256) void softargmax_finalize_kernel(const AccT* __
             if (r[1] > 0) {
                 const AccT f = acc_exp<AccT>(r[0] - M);
                 S += r[1] * f; SX += r[2] * f; SY += r[3] * f; SZ += r[4] * f;
-            }
+            } else bad = true;
         }
         S = sa_wave_sum(S); SX = sa_wave_sum(SX); SY = sa_wave_sum(SY); SZ = sa_wave_sum(SZ);
+        bad = bad || !(M - M == (AccT)0) || !(S - S == (AccT)0) || !(SX - SX == (AccT)0) || !(SY - SY == (AccT)0) || !(SZ - SZ == (AccT)0);
         if (lane == 0) {
             const AccT x01 = SX / S, y01 = SY / S, z01 = SZ / S;
             if (coords01 != nullptr) {            // net_output_to_heatmap_and_coords output (volumetric.py:234-235)
@@ -380,7 +400,9 @@ __global__ __launch_bounds__(256) void softargmax_finalize_kernel(const AccT* __
             mm[j][2] = z01 * (AccT)a.box_size_mm;
         }
     }
+    if (bad) atomicOr(&s_bad, 1);
     __syncthreads();
+    if (status != nullptr && threadIdx.x == 0) status[img] = s_bad;
     const int j = threadIdx.x;
     if (poses != nullptr && j < a.n_joints_out) {
         const int src = a.perm[j];
@@ -408,7 +430,7 @@ SoftArgmaxArgs make_softargmax_args(const MetroSpec& spec, int n) {
 
 template <typename AccT, typename LogitT>
 static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void* partials,
-                               float* poses, float* coords01, hipStream_t stream) {
+                               float* poses, float* coords01, hipStream_t stream, int32_t* status) {
     const int C = a.depth * a.n_joints_head;
     const int quads = C / 4;
     const int ppb = SA_NT / quads;
@@ -427,27 +449,27 @@ static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void
     int st = launch_status("softargmax_partial");
     if (st) return st;
     hipLaunchKernelGGL(softargmax_finalize_kernel<AccT>, dim3(a.n), dim3(256), 0, stream,
-                       static_cast<const AccT*>(partials), poses, a, slabs, coords01);
+                       static_cast<const AccT*>(partials), poses, a, slabs, coords01, status);
     return launch_status("softargmax_finalize");
 }
 
 int launch_softargmax_finalize(const float* partials, const SoftArgmaxArgs& a, int slabs, float* poses_out,
-                               hipStream_t stream, float* coords01_out) {
+                               hipStream_t stream, float* coords01_out, int32_t* status) {
     if (note_kernel("softargmax_finalize<acc32>")) return METRO_OK;
-    hipLaunchKernelGGL(softargmax_finalize_kernel<float>, dim3(a.n), dim3(256), 0, stream, partials, poses_out, a, slabs, coords01_out);
+    hipLaunchKernelGGL(softargmax_finalize_kernel<float>, dim3(a.n), dim3(256), 0, stream, partials, poses_out, a, slabs, coords01_out, status);
     return launch_status("softargmax_finalize");
 }
 
 int launch_softargmax(const void* logits, const SoftArgmaxArgs& a, int precise, void* partials,
-                      float* poses_out, hipStream_t stream, float* coords01_out) {
+                      float* poses_out, hipStream_t stream, float* coords01_out, int32_t* status) {
     const int C = a.depth * a.n_joints_head;
     if (C % 4 || C / 4 > SA_NT || a.n_joints_head > METRO_MAX_JOINTS || a.n_joints_out > 64) {
         set_error("softargmax: unsupported head (depth %d, joints %d)", a.depth, a.n_joints_head);
         return METRO_ERR_UNSUPPORTED;
     }
-    if (precise == 0) return launch_softargmax_t<float, float>(logits, a, partials, poses_out, coords01_out, stream);
-    if (precise == 1) return launch_softargmax_t<double, float>(logits, a, partials, poses_out, coords01_out, stream);
-    if (precise == 2) return launch_softargmax_t<double, double>(logits, a, partials, poses_out, coords01_out, stream);
+    if (precise == 0) return launch_softargmax_t<float, float>(logits, a, partials, poses_out, coords01_out, stream, status);
+    if (precise == 1) return launch_softargmax_t<double, float>(logits, a, partials, poses_out, coords01_out, stream, status);
+    if (precise == 2) return launch_softargmax_t<double, double>(logits, a, partials, poses_out, coords01_out, stream, status);
     set_error("softargmax: precise must be 0, 1 or 2 (got %d)", precise);
     return METRO_ERR_INVALID_ARG;
 }

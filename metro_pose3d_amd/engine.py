@@ -114,7 +114,7 @@ class Engine:
         """The kernel instantiation every layer runs on at batch n (metro_plan_layer_kernel: a dry run of the dispatch,
         no device needed).  The choice depends on the batch; tests/test_kernel_coverage.py holds every id to a test."""
         out = []
-        buf = C.create_string_buffer(256)
+        buf = C.create_string_buffer(1024)
         for i in range(self.lib.metro_plan_num_layers(self._plan)):
             check(self.lib.metro_plan_layer_kernel(self._plan, i, int(n), buf, len(buf)), 'metro_plan_layer_kernel')
             out.append(buf.value.decode())
@@ -183,6 +183,14 @@ class Engine:
                                      C.c_void_p(stream)), 'metro_forward')
         return out
 
+    def check_finite(self, n: int) -> None:
+        """Non-finite screen of the last forward(n) on this engine: raises _lib.NonFiniteError when activations overflowed
+        the arithmetic mode on their way to the soft-argmax (metro_forward_status).  Synchronises the current stream."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        bad = C.c_int32(0)
+        check(self.lib.metro_forward_status(self._plan, C.c_void_p(self._ws.data_ptr()), int(n), C.c_void_p(stream), C.byref(bad)),
+              f'{self.spec.arch_name} stride {self.spec.stride} in precision {self.precision!r}')
+
     def forward_upto(self, images: torch.Tensor, layer: int, second: bool = False) -> torch.Tensor:
         """Runs layers [0..layer] and returns that layer's output tensor [n,h,w,c] (a copy); `second` selects
         the second output of a fused launch (MetroLayerInfo.out2_offset)."""
@@ -225,6 +233,8 @@ class Engine:
 
     def close(self) -> None:
         if self._plan:
+            if self._ws is not None and self.device is not None:
+                torch.cuda.synchronize(self.device)      # queued launches still read the plan's parameter blob / workspace
             self.lib.metro_plan_destroy(self._plan)
             self._plan = C.c_void_p()
 

@@ -9,8 +9,10 @@ same CLI flag `--model-path`.  Differences that follow from not being TensorFlow
   * `model_path` is a frozen `.pb` GraphDef like the reference's (read without TensorFlow, tfgraph.py) or the
     `.npz` container of modelfile.py;
   * N is free, as with the reference's `[None, 256, 256, 3]` placeholder (main.py:109-111): the call plans for the
-    batch it is given -- one `metro_forward` for up to 256 crops (kernel dispatch depends on the batch: from 128 crops
-    on the 3x3 layers take 512-pixel tiles and more layers run on the 256 x 256 GEMM kernel), 256-crop chunks beyond.
+    batch it is given -- one `metro_forward` for up to 256 crops, 256-crop chunks beyond.  Kernel dispatch depends on the
+    crops per call (tile counts against 256 CUs: from 128 crops on the 3x3 layers take 512-pixel tiles, the head takes
+    256-pixel tiles once it has 256 of them), so results are not bit-stable ACROSS call sizes >= 128 (estimate_pose docstring);
+  * one process per GPU under torch.distributed: the same call shards the batch by image and all-gathers the poses.
 Input contract (inference.py:17-18, main.py:109-110): float32 NHWC [N,256,256,3], RGB in [0,1].
 The arithmetic mode defaults to fp16, the reference's default compute dtype (options.py:73);
 pass precision='f64' (or METRO_PRECISION=f64) for the parity mode (fp64 arithmetic inside).
@@ -18,6 +20,7 @@ pass precision='f64' (or METRO_PRECISION=f64) for the parity mode (fp64 arithmet
 from __future__ import annotations
 
 import argparse
+import contextlib
 import os
 from collections import OrderedDict
 from typing import Optional, Tuple
@@ -60,31 +63,84 @@ def _engine_for(model_path: str, precision: str, device: torch.device, n: int = 
     return eng
 
 
-def estimate_pose(images_tensor, model_path, precision: Optional[str] = None):
-    """images [N,256,256,3] float32 in [0,1] -> (poses [N,Jout,3] mm, joint_edges, joint_names)."""
-    if precision is None:
-        precision = os.environ.get('METRO_PRECISION', 'f16')
+def clear_cache() -> None:
+    """Closes every cached engine (plan, parameter blob, workspace: 2.6 GB at bucket 256) after draining its device."""
+    while _ENGINES:
+        _, eng = _ENGINES.popitem(last=False)
+        eng.close()
+
+
+def _resolve_device(images_tensor: torch.Tensor) -> torch.device:
     if not torch.cuda.is_available():
         raise _lib.MetroError('no HIP device visible: the MeTRo hot path has no CPU fallback')
+    return images_tensor.device if images_tensor.is_cuda else torch.device('cuda', torch.cuda.current_device())
+
+
+def _gather_shards(local: torch.Tensor, n_total: int, group) -> torch.Tensor:
+    """The one collective of the path: all-gather of the per-rank [n_r, Jout, 3] poses (dist.all_gather_poses).  RCCL moves
+    device tensors (backend `nccl`); any other backend (gloo in the tests) gets host tensors and the result goes back."""
+    import torch.distributed as dist
+    from metro_pose3d_amd.dist import all_gather_poses
+    if dist.get_backend(group) == 'nccl' or not local.is_cuda:
+        return all_gather_poses(local, n_total, group)
+    return all_gather_poses(local.cpu(), n_total, group).to(local.device)
+
+
+def estimate_pose(images_tensor, model_path, precision: Optional[str] = None, check_finite: Optional[bool] = None,
+                  shard: Optional[bool] = None, group=None):
+    """images [N,256,256,3] float32 in [0,1] -> (poses [N,Jout,3] mm, joint_edges, joint_names).
+
+    Multi-GPU (BASELINE.json north star; the reference's call has no such notion): when `torch.distributed` is initialised with
+    more than one rank (one process per GPU), EVERY rank makes this same call with the same N images; rank r computes the
+    contiguous shard dist.shard_range(N, r, world) on its own GPU and all ranks return the full [N,Jout,3] after ONE all-gather
+    of the poses (RCCL over xGMI under backend `nccl`).  No activation crosses ranks, so the result has the bits of the
+    single-GPU call as long as both run the same kernel instantiations: always below 128 crops per call (see below).
+    `shard=False` keeps the call local; `group` selects a process group.
+
+    Results are NOT bit-stable across call sizes: kernel tile shapes follow the crops per call (the engine buckets of 8 / 64 /
+    256; from 128 crops per call on the 3x3 layers take 512-pixel tiles; the head takes 256-pixel tiles once n * S * S / 256 >= 256)
+    and every tile shape is another fp32 summation order.  Differences are rounding flips of the fp16 chain (tests/
+    test_gpu_forward.py), calls below 128 crops agree bit for bit with one another whatever their size.
+
+    `check_finite` (default on; METRO_CHECK_FINITE=0 turns it off): after the forward, the finalize launch's non-finite screen
+    is read back (one stream synchronisation per call, as the reference's blocking sess.run) and NonFiniteError is raised when
+    activations overflowed -- a checkpoint whose residual stream exceeds fp16's 65 504 needs precision='f32m' (or 'f64')."""
+    if precision is None:
+        precision = os.environ.get('METRO_PRECISION', 'f16')
+    if check_finite is None:
+        check_finite = os.environ.get('METRO_CHECK_FINITE', '1') != '0'
     if isinstance(images_tensor, np.ndarray):
         images_tensor = torch.from_numpy(images_tensor)
     if not isinstance(images_tensor, torch.Tensor):
         raise ValueError(f'images must be a torch.Tensor or numpy array, got {type(images_tensor)}')
     if images_tensor.dtype != torch.float32:
         raise ValueError(f'images must be float32 in [0,1] (reference inference.py:18), got {images_tensor.dtype}')
-    device = images_tensor.device if images_tensor.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    device = _resolve_device(images_tensor)
     n = int(images_tensor.shape[0]) if images_tensor.dim() == 4 else 0
-    eng = _engine_for(model_path, precision, device, max(n, 1))
+    rank, world = 0, 1
+    if shard is not False:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        elif shard:
+            raise _lib.MetroError('shard=True needs an initialised torch.distributed process group with more than one rank')
+    from metro_pose3d_amd.dist import shard_range
+    begin, end = shard_range(n, rank, world) if n else (0, 0)
+    eng = _engine_for(model_path, precision, device, max(end - begin, 1))
     s = eng.spec.proc_side
     if images_tensor.dim() != 4 or tuple(images_tensor.shape[1:]) != (s, s, 3):
         raise ValueError(f'images must be NHWC [N,{s},{s},3] (reference main.py:109-110), got '
                          f'{tuple(images_tensor.shape)}')
-    images = images_tensor.to(device, non_blocking=True).contiguous()
+    images = images_tensor[begin:end].to(device, non_blocking=True).contiguous()      # only this rank's shard goes to its GPU
     sk = eng.spec.skeleton
-    poses = torch.empty((n, sk.n_out, 3), dtype=torch.float32, device=device)
-    with torch.cuda.device(device):
-        for i in range(0, n, eng.max_batch):
+    poses = torch.empty((end - begin, sk.n_out, 3), dtype=torch.float32, device=device)
+    with (torch.cuda.device(device) if device.type == 'cuda' else contextlib.nullcontext()):
+        for i in range(0, end - begin, eng.max_batch):
             eng.forward(images[i:i + eng.max_batch], out=poses[i:i + eng.max_batch])
+            if check_finite:
+                eng.check_finite(min(eng.max_batch, end - begin - i))
+        if world > 1:
+            poses = _gather_shards(poses, n, group)
     names = np.empty(sk.n_out, dtype=object)
     names[:] = sk.names_bytes()
     return poses, sk.edges_array(), names

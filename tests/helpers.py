@@ -134,3 +134,20 @@ def oracle_spec(spec):
     return OracleSpec(arch=spec.arch, stride=spec.stride, dataset=spec.dataset, depth=spec.depth,
                       centered_stride=spec.centered_stride, proc_side=spec.proc_side,
                       box_size_mm=spec.box_size_mm, base_width=spec.base_width)
+
+
+def assert_as_accurate_as_fp16_model(spec, params, images, poses, what='', ratio_mean=2.0, ratio_max=2.5):
+    """The accuracy criterion of the f16 mode: `poses` (the HIP path's, for exactly these crops) may
+    not be further from exact math (fp64 oracle) than the one-rounding-per-tensor fp16 model of the graph (oracle/f16emu.py)
+    is itself -- mean within ratio_mean, maximum within ratio_max (two draws of the same rounding noise)."""
+    from oracle import f16emu
+    from oracle import forward as OF
+    ospec = oracle_spec(spec)
+    exact = OF.forward(ospec, params, images, torch.float64).numpy()
+    emu = f16emu.forward(ospec, params, images).numpy()
+    poses = np.asarray(poses, dtype=np.float64)
+    assert np.isfinite(poses).all(), what
+    d, de = np.abs(poses - exact), np.abs(emu - exact)
+    assert d.mean() <= ratio_mean * de.mean() and d.max() <= ratio_max * de.max(), \
+        f'{what}: |hip - fp64| mean {d.mean():.3f} max {d.max():.3f} mm vs the fp16 model\'s own {de.mean():.3f} / {de.max():.3f} mm'
+    return float(d.max()), float(de.max())

@@ -79,3 +79,67 @@ def test_shard_range_partitions_exactly():
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+# ---- the drop-in call itself: estimate_pose(images, model_path) under an initialised process group -------------------------
+class _FakeEngine:
+    """Stands in for Engine in the CPU test of estimate_pose's sharding logic (the real engine needs a GPU; the real-engine
+    version of this test is tests/test_gpu_forward.py::test_estimate_pose_shards_across_ranks)."""
+
+    def __init__(self, max_batch):
+        from metro_pose3d_amd import ModelSpec
+        self.spec = ModelSpec(50, 16, 'h36m')
+        self.max_batch = max_batch
+        self.calls = []
+
+    def forward(self, images, out=None):
+        self.calls.append(int(images.shape[0]))
+        n = images.shape[0]
+        flat = images.reshape(n, -1)
+        res = torch.stack([flat[:, 1000 * j:1000 * j + 3] * (j + 1) for j in range(17)], dim=1)
+        out.copy_(res)
+        return out
+
+    def check_finite(self, n):
+        self.calls.append(('check', n))
+
+
+def _estimate_pose_worker(rank, world, port, n, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from metro_pose3d_amd import inference as INF
+        from metro_pose3d_amd.inference import batch_bucket
+        engines = {}
+
+        def engine_for(model_path, precision, device, n_call=64):
+            return engines.setdefault(batch_bucket(n_call), _FakeEngine(batch_bucket(n_call)))
+        INF._engine_for = engine_for
+        INF._resolve_device = lambda t: torch.device('cpu')
+        g = torch.Generator().manual_seed(11)
+        images = torch.rand((n, 256, 256, 3), generator=g)
+        poses, edges, names = INF.estimate_pose(images, 'unused.npz')
+        local, _, _ = INF.estimate_pose(images, 'unused.npz', shard=False)
+        b, e = shard_range(n, rank, world)
+        calls = [c for eng in engines.values() for c in eng.calls]
+        q.put((rank, bool(torch.equal(poses, local)), tuple(poses.shape), len(names), (e - b) in calls or e == b, ('check', max(e - b, 0)) in calls or e == b))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n', [(2, 10), (2, 7), (3, 4), (2, 1)])
+def test_estimate_pose_shards_by_image_and_gathers(world, n):
+    """Every rank calls estimate_pose with the same N crops: rank r forwards only shard_range(N, r, world), every rank returns
+    all N poses, identical to the unsharded call (the reference's call has one signature: inference.py:31-43)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_estimate_pose_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(world))
+    assert res == [(r, True, (n, 17, 3), 17, True, True) for r in range(world)]

@@ -50,15 +50,18 @@ CASES = [(ModelSpec(50, 32, 'h36m'), 2), (ModelSpec(50, 16, 'h36m'), 3), (ModelS
          (ModelSpec(50, 16, 'h36m', centered_stride=False), 1),
          # a second, harsher fp16 regime: conv3 at its undamped He initialisation (synth.RES_GAIN = 0.25 everywhere else keeps
          # the synthetic residual stream in the numeric range of a trained net); activations reach ~2e4 here
-         (ModelSpec(50, 16, 'h36m'), 1, {'res_gain': 1.0})]
+         (ModelSpec(50, 16, 'h36m'), 1, {'res_gain': 1.0}),
+         # the dispatch of calls with >= 128 crops (512-pixel 3x3 tiles, more layers on the 256 x 256 GEMM, from 256 crops the
+         # 256-pixel head): every launch at its REAL batch, the oracle on the first and the last crop of the call
+         (ModelSpec(50, 16, 'h36m'), 2, {'batch': 130}), (ModelSpec(50, 16, 'h36m'), 2, {'batch': 256})]
 _id = lambda c: (f'rn{c[0].arch}-s{c[0].stride}-{c[0].dataset}-n{c[1]}' + ('' if c[0].centered_stride else '-nc') +
-                 ('-undamped' if len(c) > 2 else ''))
+                 ('-undamped' if len(c) > 2 and 'res_gain' in c[2] else '') + (f'-of-batch{c[2]["batch"]}' if len(c) > 2 and 'batch' in c[2] else ''))
 
 
 def case_params(spec, extra):
     """The bench / golden parameter set of `spec`, or (extra['res_gain']) the undamped variant with its logits kernel scaled
     to the same per-joint logit std (~4) by a one-crop run of the exact oracle."""
-    if not extra:
+    if not extra or 'res_gain' not in extra:
         return synth.make_params(spec.arch, spec.n_head_channels, spec.base_width, seed=0,
                                  logit_gain=synth.logit_gain_for(spec.arch, spec.stride))
     mk = lambda lg: synth.make_params(spec.arch, spec.n_head_channels, spec.base_width, seed=0, logit_gain=lg, res_gain=extra['res_gain'])
@@ -129,7 +132,10 @@ def nhwc(t):
 def test_f16_mode_layerwise_against_fp16_oracle(cuda, case):
     spec, n = case[0], case[1]
     params = case_params(spec, case[2] if len(case) > 2 else None)
-    images = synth.make_images(n, spec.proc_side, seed=4321)
+    batch = case[2].get('batch', n) if len(case) > 2 else n
+    all_images = synth.make_images(batch, spec.proc_side, seed=4321)
+    sel = list(range(n)) if batch == n else [0, batch - 1]               # crops the oracle is computed for
+    images = all_images[sel]
     ospec = H.oracle_spec(spec)
     col = {}
     want = f16emu.forward(ospec, params, images, col).numpy()              # whole graph, fp16 model
@@ -137,12 +143,12 @@ def test_f16_mode_layerwise_against_fp16_oracle(cuda, case):
     root = f'MainPart/{ospec.arch_name}'
     units = {u.name: u for u in schedule(ospec)}
     order = list(units)
-    x = torch.from_numpy(images).to(cuda)
-    eng = Engine(spec, params, 'f16', max_batch=n, device=cuda)
+    x = torch.from_numpy(all_images).to(cuda)
+    eng = Engine(spec, params, 'f16', max_batch=batch, device=cuda)
     hip = {}                                                               # oracle key -> the HIP path's tensor (NCHW fp64)
 
     def fetch(i, second=False):
-        return eng.forward_upto(x, i, second=second).cpu().double().permute(0, 3, 1, 2).contiguous()
+        return eng.forward_upto(x, i, second=second)[sel].cpu().double().permute(0, 3, 1, 2).contiguous()
 
     def unit_input(uname):
         k = order.index(uname)
@@ -208,7 +214,7 @@ def test_f16_mode_layerwise_against_fp16_oracle(cuda, case):
             checked += 1
     assert checked >= len(eng.layer_infos()) - 1
     # ---- soft-argmax on the HIP path's own logits, then the whole graph ---------------------------------
-    poses = eng.forward(x).cpu().numpy()
+    poses = eng.forward(x)[sel].cpu().numpy()
     _, c01 = soft_argmax01(hip['logits'], ospec_joints(ospec), ospec.depth)
     d_sa = float(np.abs(poses - coords01_to_output(ospec, c01).numpy()).max())
     d_emu = float(np.abs(poses - want).max())

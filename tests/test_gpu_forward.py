@@ -222,8 +222,13 @@ def test_large_batch_tile_shapes_agree_with_small_batches(cuda):
     b = halves(lambda t: small.forward_upto(t, i)).cpu().double().numpy()
     assert not np.array_equal(a, b), 'expected the 512-pixel tiles at this batch (dispatch changed? update this test)'
     compare_fp16(a, b, 'block2/unit_1/conv2, 512-pixel vs 256-pixel tiles')
-    pa, pb = big.forward(x).cpu().numpy(), halves(small.forward).cpu().numpy()
-    assert np.isfinite(pa).all() and np.abs(pa - pb).max() < 6.0 and np.abs(pa - pb).mean() < 0.6, (np.abs(pa - pb).max(), np.abs(pa - pb).mean())
+    # the poses of BOTH dispatches are held to exact math by the accuracy criterion of the f16 mode (crops 0, 64, 65, 129: both halves'
+    # edges), not to one another by a millimetre bound; every launch of the >= 128-crop dispatch is held to a rounding flip at its
+    # real batch by tests/test_f16_layerwise.py (the batch-130 case) and tests/test_kernel_coverage.py
+    sel = [0, n // 2 - 1, n // 2, n - 1]
+    pa, pb = big.forward(x)[sel].cpu().numpy(), halves(small.forward)[sel].cpu().numpy()
+    H.assert_as_accurate_as_fp16_model(spec, params, images[sel], pa, '130 crops in one call')
+    H.assert_as_accurate_as_fp16_model(spec, params, images[sel], pb, '65 + 65 crops')
 
 
 def test_two_devices_in_one_process(cuda):
@@ -395,8 +400,10 @@ def test_estimate_pose_plans_for_the_batch_it_is_given(cuda, tmp_path, monkeypat
     calls.clear()
     p64 = torch.cat([INF.estimate_pose(x[i:i + 64], path)[0] for i in range(0, 256, 64)])
     assert calls == [(64, 64)] * 4, calls
-    a, b = p256.cpu().numpy(), p64.cpu().numpy()
-    assert np.isfinite(a).all() and np.abs(a - b).max() < 6.0 and np.abs(a - b).mean() < 0.6, (np.abs(a - b).max(), np.abs(a - b).mean())
+    sel = [0, 63, 64, 255]
+    assert torch.isfinite(p256).all() and torch.isfinite(p64).all()
+    H.assert_as_accurate_as_fp16_model(spec, params, images[sel], p256[sel].cpu().numpy(), 'estimate_pose, 256 crops in one call')
+    H.assert_as_accurate_as_fp16_model(spec, params, images[sel], p64[sel].cpu().numpy(), 'estimate_pose, 4 calls of 64 crops')
     calls.clear()
     p300, _, _ = INF.estimate_pose(x, path)
     assert calls == [(256, 256), (256, 44)], calls
@@ -451,3 +458,83 @@ def test_two_ranks_real_engine_gather_equals_single_process(cuda, n):
         assert p.exitcode == 0
     for r in range(2):
         assert res[r].shape == want.shape and np.array_equal(res[r], want), f'rank {r}: gathered poses differ from the single-process run'
+
+
+def _estimate_pose_rank(rank, world, port, path, n, q):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from metro_pose3d_amd import inference as INF
+        torch.cuda.set_device(0)                              # BOTH ranks on the one GPU of the box
+        images = torch.from_numpy(synth.make_images(n))       # host tensor: only the rank's shard is uploaded
+        poses, edges, names = INF.estimate_pose(images, path)
+        q.put((rank, poses.cpu().numpy(), str(poses.device), [int(k[-1]) for k in INF._ENGINES]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n', [16, 7, 1], ids=['even', 'ragged', 'fewer-crops-than-ranks'])
+def test_estimate_pose_shards_across_ranks(cuda, tmp_path, n):
+    """Row (e) THROUGH THE BOUNDARY: two processes under an initialised process group call estimate_pose(images, model_path)
+    with the same N crops; each forwards its contiguous shard with the real engine and every rank gets all N poses back,
+    bit-identical to the single-process call (below 128 crops per call every tile shape sums in the same order).  Both ranks
+    share cuda:0 and the all-gather runs over gloo -- what a 1-GPU box can show; under backend `nccl` the same code path gathers
+    device tensors with RCCL (bench.py --gpus N)."""
+    import socket
+    import torch.multiprocessing as mp
+    from metro_pose3d_amd import inference as INF, save_model
+    spec = ModelSpec(50, 16, 'many19')
+    params, images = _setup(spec, n, gain=synth.logit_gain_for(50, 16))
+    path = str(tmp_path / 'rn50s16j19.npz')
+    save_model(path, spec, params)
+    want = INF.estimate_pose(torch.from_numpy(images).to(cuda), path)[0].cpu().numpy()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_estimate_pose_rank, args=(r, 2, port, path, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (a, d, b) for r, a, d, b in (q.get(timeout=600) for _ in range(2))}
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(2):
+        got, dev, buckets = res[r]
+        assert dev == 'cuda:0' and got.shape == want.shape == (n, 19, 3)
+        assert np.array_equal(got, want), f'rank {r}: sharded estimate_pose differs from the single-process call'
+        assert buckets == [INF.batch_bucket(max(-(-n // 2) if r == 0 else n // 2, 1))]      # planned for the SHARD, not for N
+
+
+def test_fp16_overflow_is_reported_not_returned(cuda, tmp_path):
+    """A checkpoint whose residual stream exceeds fp16's 65 504 (here: ResNet-101 with every conv3 at 3x its He initialisation;
+    the reference keeps fp32 variables under fp16 compute for this reason, tfu.py:426-440) must not hand back NaN -- or worse,
+    finite but wrong -- poses: the finalize launch flags the crops, metro_forward_status / estimate_pose raise and name the
+    remedy, and the remedy (precision='f32m') works on the same file."""
+    from metro_pose3d_amd import inference as INF, save_model
+    spec = ModelSpec(101, 32, 'h36m')
+    params = synth.make_params(101, spec.n_head_channels, 64, seed=0, logit_gain=1e-6, res_gain=3.0)
+    images = torch.from_numpy(synth.make_images(3)).to(cuda)
+    path = str(tmp_path / 'rn101_overflowing.npz')
+    save_model(path, spec, params)
+    eng = Engine(spec, params, 'f16', max_batch=4, device=cuda)
+    poses = eng.forward(images)
+    with pytest.raises(_lib.NonFiniteError, match='f32m'):
+        eng.check_finite(3)
+    with pytest.raises(_lib.NonFiniteError, match='f32m'):
+        INF.estimate_pose(images, path)
+    silent = INF.estimate_pose(images, path, check_finite=False)[0]                # the old behaviour, on request
+    assert silent.shape == (3, 17, 3)
+    ok = INF.estimate_pose(images, path, precision='f32m')[0]
+    assert torch.isfinite(ok).all()
+    # a healthy model passes the screen in every mode and the flag is rewritten by every forward
+    good = synth.make_params(101, spec.n_head_channels, 64, seed=0, logit_gain=synth.logit_gain_for(101, 32))
+    eng2 = Engine(spec, good, 'f16', max_batch=4, device=cuda)
+    eng2.forward(images)
+    eng2.check_finite(3)
+    INF.clear_cache()
+    assert len(INF._ENGINES) == 0

@@ -84,20 +84,24 @@ def test_every_layer_names_its_kernel_without_a_gpu():
     assert k32[-1] == 'softargmax_partial<acc64,logits32> & softargmax_finalize<acc64>'
 
 
-def test_head_partials_slot_covers_large_heat_maps():
-    """The one-launch head writes one fp32 record per (image, 64-pixel slab, joint): more slabs than the two-launch path's
-    cap of 64 once the heat map has > 4096 pixels (proc_side 384 at stride 4 = 96 x 96).  The partials slot is the LAST
-    slot of the workspace: it must hold them."""
+@pytest.mark.parametrize('nb', [3, 8], ids=['64-pixel-tiles', '256-pixel-tiles'])
+def test_head_partials_slot_covers_large_heat_maps(lib, nb):
+    """The one-launch head writes one fp32 record per (image, slab, joint): one per 64 pixels, and one per 32 pixels once the
+    launch has >= 256 tiles of 256 pixels (head_f16<160x256>) -- more slabs than the two-launch path's cap of 64 once the heat
+    map has > 4096 pixels (proc_side 384 at stride 4 = 96 x 96).  The partials slot (followed only by the 4-byte-per-image
+    status words) must hold what the library itself says a launch at this batch writes."""
     spec = ModelSpec(50, 4, 'h36m', proc_side=384)
-    nb = 3
     eng = Engine(spec, None, 'f16', max_batch=nb)
     infos = eng.layer_infos()
     logits = next(li for li in infos if li.name == b'logits')
-    assert eng.layer_kernels(nb)[infos.index(logits)].startswith('head_f16')
+    kern = eng.layer_kernels(nb)[infos.index(logits)]
+    assert kern.startswith('head_f16<160x256') if nb == 8 else kern.startswith('head_f16<') and '160x256' not in kern, kern
     side, j = 96, spec.skeleton.n_head
     after_logits = logits.out_offset + logits.out_bytes_per_image * nb
-    need = nb * (side * side // 64) * j * 5 * 4
-    assert eng.workspace_bytes - after_logits >= need, (eng.workspace_bytes - after_logits, need)
+    need = lib.metro_head_f16_scratch_bytes(nb, side, j)
+    assert need >= nb * (side * side // (32 if nb == 8 else 64)) * j * 5 * 4          # the worst case at this batch: a record per 32 pixels
+    status = -(-nb * 4 // 256) * 256
+    assert eng.workspace_bytes - after_logits - status >= need, (eng.workspace_bytes - after_logits - status, need)
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------
