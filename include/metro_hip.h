@@ -252,6 +252,12 @@ int  metro_conv_f16_gemm8p(const MetroConvDesc* d, const void* d_in, const void*
 int  metro_conv_f16_gemm4w(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                            const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
                            int32_t split, void* d_out2, void* stream);
+/* The same contract and shapes with four waves of 128 x 128 AND both operands by LDS-DMA through a ring of four 32-channel slots
+ * (conv_gemm4d.hip: the geometry of gemm4w, the staging of gemm8p -- nothing passes through the issuing wave's registers on its
+ * way into LDS; one barrier per 32 MFMAs; the pre-activation on the pixel fragments).  Bit-identical to the other two. */
+int  metro_conv_f16_gemm4d(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
+                           const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
+                           int32_t split, void* d_out2, void* stream);
 /* Stem 7x7/2 convolution (+bias) and zero-padded 3x3/2 max-pool in one launch (reference resnet_v2.py:219-224,
  * resnet_utils.py:138-185).  d_prepped = metro_prep_input_f16 output [n,side+6,side+8,4] fp16, d_w packed
  * [64][7][8][4] fp16, d_out fp16 [n,side/4,side/4,64].  side % 32 == 0. */

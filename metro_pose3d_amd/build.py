@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(HERE, 'libmetro_hip.so')
-SOURCES = ['conv_igemm_f16_dma.hip', 'conv_gemm8p.hip', 'conv_gemm4w.hip', 'conv3x3_f16_slab.hip', 'conv3x3_c64.hip', 'conv_pw64.hip', 'head_f16.hip', 'stem_pool_f16.hip', 'conv_igemm_f64acc.hip', 'conv_igemm_f32.hip', 'pool_softargmax.hip', 'eval_metrics.hip', 'heads.hip', 'plan.cpp']
+SOURCES = ['conv_igemm_f16_dma.hip', 'conv_gemm8p.hip', 'conv_gemm4w.hip', 'conv_gemm4d.hip', 'conv3x3_f16_slab.hip', 'conv3x3_c64.hip', 'conv_pw64.hip', 'head_f16.hip', 'stem_pool_f16.hip', 'conv_igemm_f64acc.hip', 'conv_igemm_f32.hip', 'pool_softargmax.hip', 'eval_metrics.hip', 'heads.hip', 'plan.cpp']
 HEADERS = ['metro_common.h', os.path.join('..', '..', 'include', 'metro_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-Wall',
          '-Wno-unused-function'] + os.environ.get('METRO_EXTRA_HIPCC_FLAGS', '').split()

@@ -701,7 +701,13 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
         // the four-wave form (128 x 128 wave tiles, register-staged operands, the pre-activation applied once per element on the
         // way into LDS) is 3-11 % ahead on every pre-activated layer (all of conv1 / shortcut / pair), batch 64-256; the bare GEMM
         // is faster on the 8-phase kernel (tools/gemm8p_probe.py).  Same K order: the two give the same bits.
+        // ... and that geometry with BOTH operands by LDS-DMA in full 128-byte row pieces and a four-deep fragment pipeline
+        // (conv_gemm4d.hip, round 4: the structure of the library's own best kernel) is 2-8 % ahead of it on every pre-activated
+        // shape in isolation (tools/gemm8p_probe.py) and 0.2-0.7 % BEHIND inside the forward (tools/ab_bench.sh, same box, batch 64
+        // and 256): kept behind the knob, off.  Same bits again.
         static const int four = env_int("METRO_GEMM4W", 1);
+        static const int four_d = env_int("METRO_GEMM4D", 0);
+        if (four_d && d.has_prologue) return launch_conv_gemm4d(d, in_, w_, bias, ps_, pb_, res_, out, stream, split);
         if (four && d.has_prologue) return launch_conv_gemm4w(d, in_, w_, bias, ps_, pb_, res_, out, stream, split);
         return launch_conv_gemm8p(d, in_, w_, bias, ps_, pb_, res_, out, stream, split);
     }

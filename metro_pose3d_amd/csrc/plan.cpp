@@ -1020,6 +1020,21 @@ int metro_conv_f16_gemm4w(const MetroConvDesc* d, const void* d_in, const void* 
                               static_cast<hipStream_t>(stream), split > 0 ? &sp : nullptr);
 }
 
+int metro_conv_f16_gemm4d(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
+                          const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
+                          int32_t split, void* d_out2, void* stream) {
+    int st = validate_conv_desc(d);
+    if (st) return st;
+    METRO_CHECK_ARG(d_in && d_w && d_bias && d_out, "conv_f16_gemm4d: NULL tensor pointer");
+    METRO_CHECK_ARG(!d->has_prologue || (d_pro_scale && d_pro_shift), "conv_f16_gemm4d: prologue tensors missing");
+    METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f16_gemm4d: residual tensor missing");
+    METRO_CHECK_ARG(split >= 0 && split < d->c_out && (split == 0 || d_out2), "conv_f16_gemm4d: bad split %d / missing second output", split);
+    ConvSplit sp;
+    sp.split = split; sp.c_out2 = d->c_out - split; sp.relu2 = 1; sp.out2 = d_out2;
+    return launch_conv_gemm4d(*d, d_in, d_w, d_bias, d_pro_scale, d_pro_shift, d_residual, d_out,
+                              static_cast<hipStream_t>(stream), split > 0 ? &sp : nullptr);
+}
+
 int metro_stem_pool_f16(const void* d_prepped, const void* d_w, const float* d_bias, void* d_out, int32_t n,
                         int32_t side, void* stream) {
     METRO_CHECK_ARG(d_prepped && d_w && d_bias && d_out, "stem_pool_f16: NULL tensor pointer");

@@ -260,22 +260,44 @@ __global__ __launch_bounds__(SA_NT) void softargmax_partial_kernel(
     if (pp < ppb) {
         const LogitT* base = logits + (size_t)img * pixels * C + q * 4;
         typedef LogitT logit4 __attribute__((ext_vector_type(4)));
-        for (int p = p_begin + pp; p < p_end; p += ppb) {
-            const logit4 v = *reinterpret_cast<const logit4*>(base + (size_t)p * C);
-            const int h = p / side;
-            const int wq = p - h * side;
-            const AccT cx = (AccT)((float)wq * step_s);
-            const AccT cy = (AccT)((float)h * step_s);
+        // The path is HBM bound and every pixel lane has ONE 16-byte load per pixel: UNR pixels are requested before the first
+        // is consumed -- with one load in flight per thread the launch ran at 3.3 TB/s at the configs[4] volume (8 blocks x 238
+        // lanes x 16 B = 30 KB in flight per CU).  The online softmax is BRANCH FREE: per channel the running maximum is raised to
+        // the maximum of the UNR new logits first (one rescale exp per channel and iteration; exp(0) = 1 exactly when it did not
+        // move), pixels past the slab enter as -inf and contribute exp(-inf) = 0; a per-element `if (x > m)` cost a compare, an
+        // exec-mask save / restore and a branch per logit.  Pixel coordinates advance incrementally (no division in the loop).
+#ifndef METRO_SA_UNR
+#define METRO_SA_UNR 2     // measured at the configs[4] volume (285 MB): 2 -> 67.6 us, 4 -> 69.3, 8 -> 88.7 (registers cut the occupancy); 1 (round 3) -> 87
+#endif
+        constexpr int UNR = METRO_SA_UNR;
+        int ph = (p_begin + pp) / side, pw = (p_begin + pp) - ph * side;       // pixel of this lane, advanced by ppb per slot
+        for (int p0 = p_begin + pp; p0 < p_end; p0 += UNR * ppb) {
+            logit4 v[UNR];
+            AccT cx[UNR], cy[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int p = p0 + u * ppb;
+                const bool ok = p < p_end;
+                v[u] = *reinterpret_cast<const logit4*>(base + (size_t)(ok ? p : p0) * C);
+                cx[u] = (AccT)((float)pw * step_s);
+                cy[u] = (AccT)((float)ph * step_s);
+                if (!ok) { v[u][0] = v[u][1] = v[u][2] = v[u][3] = (LogitT)-INFINITY; }
+                pw += ppb;
+                while (pw >= side) { pw -= side; ++ph; }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const AccT x = (AccT)v[e];
-                if (x > m[e]) {                      // rare after the first few pixels
-                    const AccT f = acc_exp<AccT>(m[e] - x);   // exp(-inf) = 0 on first touch
-                    s[e] *= f; sx[e] *= f; sy[e] *= f;
-                    m[e] = x;
+                AccT mx = m[e];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) mx = (AccT)v[u][e] > mx ? (AccT)v[u][e] : mx;
+                const AccT f = acc_exp<AccT>(m[e] - mx);          // exp(-inf) = 0 on first touch
+                AccT s_ = s[e] * f, sx_ = sx[e] * f, sy_ = sy[e] * f;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const AccT ex = acc_exp<AccT>((AccT)v[u][e] - mx);
+                    s_ += ex; sx_ += ex * cx[u]; sy_ += ex * cy[u];
                 }
-                const AccT ex = acc_exp<AccT>(x - m[e]);
-                s[e] += ex; sx[e] += ex * cx; sy[e] += ex * cy;
+                m[e] = mx; s[e] = s_; sx[e] = sx_; sy[e] = sy_;
             }
         }
 #pragma unroll
@@ -286,26 +308,44 @@ __global__ __launch_bounds__(SA_NT) void softargmax_partial_kernel(
     }
     __syncthreads();
 
-    // fold: one thread per joint
+    // fold, stage 1: one thread per CHANNEL folds the pixel lanes (a serial walk of one thread per joint over ppb * depth = 56
+    // records was the tail of every block); the result replaces lane 0's record
+    for (int c = tid; c < C; c += SA_NT) {               // C > 256 for the 53-joint head
+        AccT M = (AccT)-INFINITY;
+        for (int l = 0; l < ppb; ++l) {
+            const AccT mv = red[((size_t)l * C + c) * 4];
+            M = mv > M ? mv : M;
+        }
+        AccT S = 0, SX = 0, SY = 0;
+        for (int l = 0; l < ppb; ++l) {
+            const AccT* r = red + ((size_t)l * C + c) * 4;
+            if (r[1] > 0) {
+                const AccT f = acc_exp<AccT>(r[0] - M);
+                S += r[1] * f; SX += r[2] * f; SY += r[3] * f;
+            } else if (r[1] != r[1]) S = r[1];           // a NaN sum must reach the finalize launch's non-finite screen
+        }
+        AccT* r0 = red + (size_t)c * 4;                  // lane 0's record of this channel: read above by this thread only
+        r0[0] = M; r0[1] = S; r0[2] = SX; r0[3] = SY;
+    }
+    __syncthreads();
+    // stage 2: one thread per joint folds its `depth` channels (c = d * nj + j, volumetric.py:231)
     if (tid < nj) {
         const int j = tid;
         const float step_d = 1.0f / (float)(depth - 1);
         AccT M = (AccT)-INFINITY;
-        for (int l = 0; l < ppb; ++l)
-            for (int d = 0; d < depth; ++d) {
-                const AccT mv = red[((size_t)l * C + d * nj + j) * 4];
-                M = mv > M ? mv : M;
-            }
+        for (int d = 0; d < depth; ++d) {
+            const AccT mv = red[(size_t)(d * nj + j) * 4];
+            M = mv > M ? mv : M;
+        }
         AccT S = 0, SX = 0, SY = 0, SZ = 0;
-        for (int l = 0; l < ppb; ++l)
-            for (int d = 0; d < depth; ++d) {
-                const AccT* r = red + ((size_t)l * C + d * nj + j) * 4;
-                if (r[1] > 0) {
-                    const AccT f = acc_exp<AccT>(r[0] - M);
-                    const AccT cz = (AccT)((float)d * step_d);
-                    S += r[1] * f; SX += r[2] * f; SY += r[3] * f; SZ += r[1] * f * cz;
-                }
-            }
+        for (int d = 0; d < depth; ++d) {
+            const AccT* r = red + (size_t)(d * nj + j) * 4;
+            if (r[1] > 0) {
+                const AccT f = acc_exp<AccT>(r[0] - M);
+                const AccT cz = (AccT)((float)d * step_d);
+                S += r[1] * f; SX += r[2] * f; SY += r[3] * f; SZ += r[1] * f * cz;
+            } else if (r[1] != r[1]) S = r[1];
+        }
         AccT* o = partials + (((size_t)img * slabs + slab) * nj + j) * 5;
         o[0] = M; o[1] = S; o[2] = SX; o[3] = SY; o[4] = SZ;
     }

@@ -563,7 +563,7 @@ G8_CASES = [('k128', 2, 128, 256, 'plain'), ('k256_relu', 3, 256, 512, 'relu'), 
 
 
 @pytest.mark.parametrize('case', G8_CASES, ids=[c[0] for c in G8_CASES])
-@pytest.mark.parametrize('kernel', ['gemm8p', 'gemm4w'])
+@pytest.mark.parametrize('kernel', ['gemm8p', 'gemm4w', 'gemm4d'])
 def test_conv_gemm8p(lib, cuda, case, kernel):
     """Every element against fp64 on the same fp16 operands: 2e-3 of the layer maximum (fp16 output rounding), for the
     plain / ReLU / pre-activation / shortcut epilogues and the fused shortcut+conv1 pair routing (reference
@@ -624,11 +624,11 @@ def test_conv_gemm8p(lib, cuda, case, kernel):
             junk.fill_(it)
         h1, h2 = run()
         assert torch.equal(h1, g1) and (not split or torch.equal(h2, g2)), f'{name}: launch {it} differs'
-    if kernel == 'gemm4w':                            # same K order, one fp32 accumulator per output: the two kernels give the same bits
+    if kernel != 'gemm8p':                            # same K order, one fp32 accumulator per output: the two kernels give the same bits
         check(lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(tx), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr),
                                         H.ptr(out), split, H.ptr(out2), C.c_void_p(0)), 'metro_conv_f16_gemm8p')
         torch.cuda.synchronize()
-        assert torch.equal(out, g1) and (not split or torch.equal(out2, g2)), f'{name}: gemm4w and gemm8p differ'
+        assert torch.equal(out, g1) and (not split or torch.equal(out2, g2)), f'{name}: {kernel} and gemm8p differ'
 
 
 def test_conv_gemm8p_rejects_partial_tiles(lib, cuda):

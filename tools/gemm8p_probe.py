@@ -15,13 +15,15 @@ lib = _lib.load()
 dev = torch.device('cuda', 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 SHAPES = [(2048, 512), (1024, 256), (1024, 2048), (512, 1024), (1024, 512)]
+if len(sys.argv) > 2:
+    SHAPES = SHAPES[:int(sys.argv[2])]
 rng = np.random.default_rng(0)
 for c_in, c_out in SHAPES:
     x = torch.from_numpy(rng.standard_normal((n, 16, 16, c_in)).astype(np.float16)).to(dev)
     w = torch.from_numpy((rng.standard_normal((c_out, c_in)) * np.sqrt(2.0 / c_in)).astype(np.float16)).to(dev)
     b = torch.zeros(c_out, dtype=torch.float32, device=dev)
-    sc = torch.ones(c_in, dtype=torch.float16, device=dev)
-    sh = torch.zeros(c_in, dtype=torch.float16, device=dev)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, c_in).astype(np.float16)).to(dev)
+    sh = torch.from_numpy((rng.standard_normal(c_in) * 0.3).astype(np.float16)).to(dev)
     out = torch.empty((n, 16, 16, c_out), dtype=torch.float16, device=dev)
     gf = 2.0 * n * 256 * c_in * c_out / 1e9
     for pro in (False, True):
@@ -29,12 +31,16 @@ for c_in, c_out in SHAPES:
         o8, o4 = torch.empty_like(out), torch.empty_like(out)
         a8 = lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(o8), 0, None, C.c_void_p(0))
         a4 = lib.metro_conv_f16_gemm4w(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(o4), 0, None, C.c_void_p(0))
+        od = torch.empty_like(out)
+        ad = lib.metro_conv_f16_gemm4d(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(od), 0, None, C.c_void_p(0))
         torch.cuda.synchronize()
-        print('   bits equal to gemm8p:', a8, a4, bool(torch.equal(o8, o4)), float((o8.float() - o4.float()).abs().max()))
+        print('   bits equal to gemm8p:', a8, a4, ad, bool(torch.equal(o8, o4)), bool(torch.equal(o8, od)), float((o8.float() - od.float()).abs().max()))
         res = {}
         for name, fn in (('gemm8p', lambda: lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
                                                                      H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
                          ('gemm4w', lambda: lib.metro_conv_f16_gemm4w(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
+                                                                     H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
+                         ('gemm4d', lambda: lib.metro_conv_f16_gemm4d(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
                                                                      H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
                          ('hipblaslt', lambda: (torch.mm(x.view(-1, c_in), w.t(), out=out.view(-1, c_out)), 0)[1]),
                          ):
