@@ -549,7 +549,11 @@ def main():
             out['c5_shard'] = side_workload(device, dist, 50, 4, 'h36m', 16, 10, 3, 'configs[4]: batch 128 sharded over 8 GPUs')
             out['boundary'] = boundary_leg(device, dist, spec, params, 256, 10, 2)
             # the HBM-bound number SURVEY 8(d) asks for next to the MFMA one: the soft-argmax on its own
-            out['softargmax_hbm'] = {'c5_volume': softargmax_hbm_leg(device, dist, 4, 'h36m', 128, 20, 3, 'configs[4] volume (S = 64, J = 17), 128 crops'),
+            out['softargmax_hbm'] = {'note': 'pure-read launch: 2 x FETCH only.  Yardsticks on the same 285 MB on this chip (tools/hbm_read_probe.py, '
+                                             'profiles/r04_hbm_read_probe.txt): torch.sum 3.9 TB/s, torch.max 3.5 TB/s (the ROCm stack\'s own read-only '
+                                             'reductions), copy 5.4 TB/s and exp 6.0 TB/s of read + write traffic; MI355X_MICROARCH.md: 6.29 TB/s float4 copy = '
+                                             '79 % of the 8 TB/s this fraction is taken of',
+                                     'c5_volume': softargmax_hbm_leg(device, dist, 4, 'h36m', 128, 20, 3, 'configs[4] volume (S = 64, J = 17), 128 crops'),
                                      'c2_volume': softargmax_hbm_leg(device, dist, 16, 'h36m', 64, 50, 5, 'configs[1] volume (S = 16, J = 17), 64 crops'),
                                      'c2_volume_b2048': softargmax_hbm_leg(device, dist, 16, 'h36m', 2048, 20, 3, 'configs[1] volume, 2048 crops (same bytes as the C5 case)')}
     if world > 1 and not args.no_extras and args.precision == 'f16':
