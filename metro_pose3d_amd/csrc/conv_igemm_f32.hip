@@ -1,6 +1,6 @@
 // fp32 implicit-GEMM convolution on the fp32 matrix cores: the parity mode at fp32 SPEED (precision METRO_PREC_F32M).
 //
-// The f64 parity mode (conv_igemm_f64acc.hip) is what sits under the 1e-3 mm bar, at 2 340 crops/s.  This kernel is the
+// The f64 parity mode (conv_igemm_f64acc.hip) is what sits under the 1e-3 mm bar, at 3 390 crops/s.  This kernel is the
 // arithmetic of the reference's own fp32 graph instead (reference src/options.py:73 `--dtype=float32`, the TF kernels of
 // resnet_v2.py:123-136,219-220,233-236 / resnet_utils.py:82-135): fp32 activations in HBM, fp32 (BN-folded in fp64, rounded
 // once) weights, every product and sum on v_mfma_f32_32x32x2_f32 -- exact fp32 products, fp32 accumulation in ascending k
