@@ -234,7 +234,10 @@ __global__ __launch_bounds__(f64k::NT, 2) void conv_igemm_f64acc_kernel(
 template <typename TIn, typename TAct>
 static int launch_t(const ConvArgs& a, const MetroConvDesc& d, bool pro, const void* in, const double* w, const double* bias,
                     const double* ps, const double* pb, const void* res, void* out, hipStream_t stream) {
-    const bool small = a.c_out <= 64;
+    // 64-cout tiles for the 64-channel layers, and wherever 128-cout tiles would leave the 256 CUs with fewer than two blocks each
+    // (two co-resident blocks are what overlaps one block's gather / commit / barrier with the other's MFMAs)
+    const long tiles128 = (long)((a.c_out + 127) / 128) * ((a.m_total + f64k::TMP - 1) / f64k::TMP);
+    const bool small = a.c_out <= 64 || tiles128 < 512;
     const bool vec2 = d.c_in % 2 == 0 && d.in_pix_stride % 2 == 0;      // 16-byte (fp64) / 8-byte (fp32) gathers of two consecutive channels
     if (note_kernel("conv_igemm_f64acc<in%d,act%d,128x%d%s%s>%s", (int)sizeof(TIn) * 8, (int)sizeof(TAct) * 8, small ? 64 : 128, vec2 ? ",v2" : "",
                     pro ? ",pro" : "", res ? "+res" : ""))
