@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define METRO_ABI_VERSION 6
+#define METRO_ABI_VERSION 7
 
 typedef enum MetroStatus {
     METRO_OK = 0,
@@ -258,6 +258,11 @@ int  metro_conv_f16_gemm4w(const MetroConvDesc* d, const void* d_in, const void*
 int  metro_conv_f16_gemm4d(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                            const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
                            int32_t split, void* d_out2, void* stream);
+/* ... and with the block tile chosen: geometry 0 = 256 couts x 256 pixels (metro_conv_f16_gemm4d), 1 = 128 x 128 (wave tiles of
+ * 64 x 64, two blocks per CU; c_out % 128 == 0, pixels % 128 == 0), 2 = 128 couts x 256 pixels.  Same K order, same bits. */
+int  metro_conv_f16_gemm4d_geo(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
+                               const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
+                               int32_t split, void* d_out2, int32_t geometry, void* stream);
 /* Stem 7x7/2 convolution (+bias) and zero-padded 3x3/2 max-pool in one launch (reference resnet_v2.py:219-224,
  * resnet_utils.py:138-185).  d_prepped = metro_prep_input_f16 output [n,side+6,side+8,4] fp16, d_w packed
  * [64][7][8][4] fp16, d_out fp16 [n,side/4,side/4,64].  side % 32 == 0. */

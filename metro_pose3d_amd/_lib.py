@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('METRO_HIP_LIB') or os.path.join(HERE, 'libmetro_hip.so')   # override: timing experiments
 
 METRO_MAX_JOINTS = 64
-ABI_VERSION = 6          # include/metro_hip.h METRO_ABI_VERSION
+ABI_VERSION = 7          # include/metro_hip.h METRO_ABI_VERSION
 METRO_PREC_F16, METRO_PREC_F32, METRO_PREC_F64, METRO_PREC_F32M = 0, 1, 2, 3
 METRO_F16, METRO_F32, METRO_F64 = 0, 1, 2
 PARAM_CONV_W, PARAM_BIAS, PARAM_PRO_SCALE, PARAM_PRO_SHIFT = 0, 1, 2, 3
@@ -85,6 +85,7 @@ SIGNATURES = {
     'metro_conv_f16_gemm8p': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
     'metro_conv_f16_gemm4w': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
     'metro_conv_f16_gemm4d': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
+    'metro_conv_f16_gemm4d_geo': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, C.c_int32, _P]),
     'metro_conv_f16_conv1_conv2': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f16_next_proj': (C.c_int, [C.POINTER(MetroConvDesc)] + [_P] * 14 + [C.c_int32, _P]),
     'metro_conv_f16_next': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),

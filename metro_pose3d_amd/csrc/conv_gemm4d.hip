@@ -38,15 +38,24 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 namespace g4d {
-constexpr int TM = 256, TN = 256, BK = 64, NT = 256;
+constexpr int BK = 64, NT = 256;
 constexpr int ROW_BYTES = BK * 2;                  // 128
-constexpr int OPER_BYTES = 256 * ROW_BYTES;        // one operand image of a K tile: 32 KiB
-constexpr int B_BASE = 2 * OPER_BYTES;             // [A buf0 | A buf1 | B buf0 | B buf1]: the buffer is a 32 KiB immediate on every ds_read
-constexpr int RING_BYTES = 4 * OPER_BYTES;         // 128 KiB
-constexpr int OUT_ROW_BYTES = TM * 2 + 16;
-constexpr int OUT_BYTES = TN * OUT_ROW_BYTES;      // 135168
-constexpr int MAIN_BYTES = OUT_BYTES > RING_BYTES ? OUT_BYTES : RING_BYTES;
 constexpr int PRO_BYTES = 2 * 2048 * 2;            // scale | shift, c_in <= 2048
+// MI x NJ 32 x 32 MFMA tiles per wave; 2 x 2 waves: block tile 64 MI couts x 64 NJ pixels
+template <int MI, int NJ>
+struct Geo {
+    static constexpr int TM = 64 * MI, TN = 64 * NJ;
+    static constexpr int OPER_A = TM * ROW_BYTES, OPER_B = TN * ROW_BYTES;      // one operand image of a K tile
+    static constexpr int B_BASE = 2 * OPER_A;                                    // [A buf0 | A buf1 | B buf0 | B buf1]
+    static constexpr int RING_BYTES = 2 * (OPER_A + OPER_B);
+    static constexpr int OUT_ROW_BYTES = TM * 2 + 16;
+    static constexpr int OUT_BYTES = TN * OUT_ROW_BYTES;
+    static constexpr int MAIN_BYTES = OUT_BYTES > RING_BYTES ? OUT_BYTES : RING_BYTES;
+    static constexpr int RA = 2 * MI, RB = 2 * NJ, R = RA + RB;                  // LDS-DMA requests per wave and K tile
+    static constexpr int Q = (R + 2) / 3;                                        // ... issued per k step (k steps 2, 3 and 0)
+    static constexpr int SLOTS = 2 * MI;                                         // request slots of a k step (two per MFMA segment)
+    static_assert(Q <= SLOTS, "request schedule does not fit the k steps");
+};
 }  // namespace g4d
 
 __device__ __forceinline__ int g4d_swz(int row) { return (row >> 1) & 7; }
@@ -65,19 +74,33 @@ __device__ __forceinline__ void g4d_dma16(const void* sbase, unsigned voff, unsi
         : "v"(voff), "s"(sbase), "s"(lds_base), "n"(LDS_IMM)
         : "scc");
 }
+template <int N>
+__device__ __forceinline__ void g4d_wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+// f(integral_constant<0>) ... f(integral_constant<N - 1>)
+template <int N, typename F>
+__device__ __forceinline__ void g4d_for(F&& f) {
+    if constexpr (N > 0) {
+        g4d_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
-template <bool PROLOGUE>
-__global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
+template <bool PROLOGUE, int MI, int NJ>
+__global__ __launch_bounds__(g4d::NT, (MI * NJ <= 4 ? 2 : 1)) void conv_gemm4d_kernel(
     ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w, const float* __restrict__ bias,
     const half_t* __restrict__ pro_scale, const half_t* __restrict__ pro_shift, const half_t* __restrict__ residual,
     half_t* __restrict__ out, half_t* __restrict__ out2, int tiles_m) {
     using namespace g4d;
+    using G = Geo<MI, NJ>;
+    constexpr int TM = G::TM, TN = G::TN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1;            // 128-cout half
-    const int wc = wave & 1;             // 128-pixel half
+    const int wr = wave >> 1;            // cout half
+    const int wc = wave & 1;             // pixel half
 
     // XCD-aware (bijective) block -> tile map: the blocks of one XCD share pixel tiles in their L2
     const int nblk = gridDim.x;
@@ -95,19 +118,20 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
     const int K = a.c_in;
     const int nk = K / BK;               // even (the launcher guarantees c_in % 128 == 0)
     const unsigned smem_base = (unsigned)(size_t)(g4d_lds_void_t*)smem;
-    half_t* pro_lds = reinterpret_cast<half_t*>(smem + MAIN_BYTES);
+    half_t* pro_lds = reinterpret_cast<half_t*>(smem + G::MAIN_BYTES);
 
     // ---- LDS-DMA sources.  One instruction = 8 rows x 128 B (lane l: row l >> 3, physical chunk l & 7 = logical chunk ^ swz(row)).
-    // An operand image of a K tile = 32 instructions; wave w issues eight: row groups 4 e + w (e = 0..7), i.e. rows 32 e + 8 w + ...
+    // Wave w issues row groups 4 e + w (e = 0..), i.e. rows 32 e + 8 w + ...: 2 MI requests for the cout image, 2 NJ for the pixels
     const int lrow = lane >> 3, lch = lane & 7;
-    unsigned voff[8];              // per-lane byte offset from the operand base of the tile (the same for both operands)
+    constexpr int RMAX = G::RA > G::RB ? G::RA : G::RB;
+    unsigned voff[RMAX];           // per-lane byte offset from the operand base of the tile (the same for both operands)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < RMAX; ++e) {
         const int row = (4 * e + wave) * 8 + lrow;
         voff[e] = (unsigned)(row * K + ((lch ^ g4d_swz(row)) * 8)) * 2u;
     }
     const unsigned lds_a = __builtin_amdgcn_readfirstlane(smem_base + wave * 8 * ROW_BYTES);            // group e adds e * 4 KiB
-    const unsigned lds_b = lds_a + B_BASE;
+    const unsigned lds_b = lds_a + G::B_BASE;
 #ifdef METRO_DBG_G4D_SAME_TILE                     // timing experiment: every block streams tile (0, 0): all requests hit the L2
     const half_t* wbase = w;
     const half_t* xbase = in;
@@ -115,39 +139,36 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
     const half_t* wbase = w + (size_t)n0 * K;      // wave-uniform operand bases of this tile
     const half_t* xbase = in + (size_t)m0 * K;
 #endif
-    // request e (0..7) of an operand image of K tile kt into buffer BUF
-    auto req_a = [&](auto buf_c, auto e_c, int kt) {
-        constexpr int BUF = decltype(buf_c)::value, E = decltype(e_c)::value;
-        g4d_dma16<BUF * OPER_BYTES + E * 4096>(wbase + kt * BK, voff[E], lds_a);
-    };
-    auto req_b = [&](auto buf_c, auto e_c, int kt) {
-        constexpr int BUF = decltype(buf_c)::value, E = decltype(e_c)::value;
-        g4d_dma16<BUF * OPER_BYTES + E * 4096>(xbase + kt * BK, voff[E], lds_b);
+    // request g (0 .. R - 1: the pixel image first -- first touch from HBM --, then the cout image) of K tile kt into buffer BUF
+    auto req = [&](auto buf_c, auto g_c, int kt) {
+        constexpr int BUF = decltype(buf_c)::value, GI = decltype(g_c)::value;
+#ifndef METRO_DBG_G4D_NO_DMA
+        if constexpr (GI < G::RB) g4d_dma16<BUF * G::OPER_B + GI * 4096>(xbase + kt * BK, voff[GI], lds_b);
+        else if constexpr (GI < G::R) g4d_dma16<BUF * G::OPER_A + (GI - G::RB) * 4096>(wbase + kt * BK, voff[GI - G::RB], lds_a);
+#endif
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
-    using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
 
-    floatx16 acc[4][4];
+    floatx16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int frag_row = lane & 31, frag_half = lane >> 5;
-    unsigned a_base[4], b_base[4];       // fragment addresses (buffer 0, k step 0); k step kk: XOR kk << 5 (the swizzle is an XOR)
+    unsigned a_base[MI], b_base[NJ];     // fragment addresses (buffer 0, k step 0); k step kk: XOR kk << 5 (the swizzle is an XOR)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wr * 128 + i * 32 + frag_row;
+    for (int i = 0; i < MI; ++i) {
+        const int row = wr * (TM / 2) + i * 32 + frag_row;
         a_base[i] = row * ROW_BYTES + ((frag_half ^ g4d_swz(row)) << 4);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wc * 128 + j * 32 + frag_row;
-        b_base[j] = B_BASE + row * ROW_BYTES + ((frag_half ^ g4d_swz(row)) << 4);
+    for (int j = 0; j < NJ; ++j) {
+        const int row = wc * (TN / 2) + j * 32 + frag_row;
+        b_base[j] = G::B_BASE + row * ROW_BYTES + ((frag_half ^ g4d_swz(row)) << 4);
     }
 
     // ---- prologue: the table, K tile 0, and of tile 1 what the loop would have requested by now; tile 0 landed --------------------
@@ -156,27 +177,27 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
         // DMAs would be waited for with vmcnt(0), and being the oldest requests they are covered by every counted wait below
         const int idx = wave * 512 + lane * 8;
         if (wave * 512 < K) {
-            const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + MAIN_BYTES + wave * 1024);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + G::MAIN_BYTES + wave * 1024);
             g4d_dma16<0>(pro_scale, (unsigned)((idx < K ? idx : 0) * 2), dst);
             g4d_dma16<4096>(pro_shift, (unsigned)((idx < K ? idx : 0) * 2), dst);
         }
     }
-    req_b(I0{}, I0{}, 0); req_b(I0{}, I1{}, 0); req_b(I0{}, I2{}, 0); req_b(I0{}, I3{}, 0);
-    req_b(I0{}, I4{}, 0); req_b(I0{}, I5{}, 0); req_b(I0{}, I6{}, 0); req_b(I0{}, I7{}, 0);
-    req_a(I0{}, I0{}, 0); req_a(I0{}, I1{}, 0); req_a(I0{}, I2{}, 0); req_a(I0{}, I3{}, 0);
-    req_a(I0{}, I4{}, 0); req_a(I0{}, I5{}, 0); req_a(I0{}, I6{}, 0); req_a(I0{}, I7{}, 0);
+    g4d_for<G::R>([&](auto g_c) { req(I0{}, g_c, 0); });
+    constexpr int HEAD = 2 * G::Q < G::R ? 2 * G::Q : G::R;       // requests of a tile that k steps 2 and 3 issue
     {
         const int k1 = nk > 1 ? 1 : 0;
-        req_b(I1{}, I0{}, k1); req_b(I1{}, I1{}, k1); req_b(I1{}, I2{}, k1); req_b(I1{}, I3{}, k1);
-        req_b(I1{}, I4{}, k1); req_b(I1{}, I5{}, k1); req_b(I1{}, I6{}, k1); req_b(I1{}, I7{}, k1);
-        req_a(I1{}, I0{}, k1); req_a(I1{}, I1{}, k1); req_a(I1{}, I2{}, k1); req_a(I1{}, I3{}, k1);
+        g4d_for<HEAD>([&](auto g_c) { req(I1{}, g_c, k1); });
     }
-    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");       // tile 0 (and the table) landed everywhere
+#ifdef METRO_DBG_G4D_NO_DMA
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    g4d_wait_vm_barrier<HEAD>();                                  // tile 0 (and the table) landed everywhere
+#endif
 
     // FOUR fragment sets, one per k step of a K tile: while the MFMAs of k step kk run on set kk, the pixel fragments of set kk + 1
     // (read during k step kk - 1) are pre-activated and set kk + 2 is read -- neither a VALU op nor an MFMA ever waits for an LDS
     // read of its own k step (one wave per SIMD issues in order: a waiting VALU op holds up every MFMA behind it)
-    half8_t af[4][4], bf[4][4];
+    half8_t af[4][MI], bf[4][NJ];
     half8_t sc[4] = {}, sh[4] = {};      // the pre-activation of a set's 8 channels per lane
     auto read_pro = [&](auto kk_c, int kt) {
         constexpr int KK = decltype(kk_c)::value;
@@ -187,11 +208,11 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
     };
     auto read_b = [&](auto buf_c, auto kk_c, int j) {
         constexpr int BUF = decltype(buf_c)::value, KK = decltype(kk_c)::value;
-        bf[KK][j] = *reinterpret_cast<const half8_t*>(smem + BUF * OPER_BYTES + (b_base[j] ^ (KK << 5)));
+        bf[KK][j] = *reinterpret_cast<const half8_t*>(smem + BUF * G::OPER_B + (b_base[j] ^ (KK << 5)));
     };
     auto read_a = [&](auto buf_c, auto kk_c, int i) {
         constexpr int BUF = decltype(buf_c)::value, KK = decltype(kk_c)::value;
-        af[KK][i] = *reinterpret_cast<const half8_t*>(smem + BUF * OPER_BYTES + (a_base[i] ^ (KK << 5)));
+        af[KK][i] = *reinterpret_cast<const half8_t*>(smem + BUF * G::OPER_A + (a_base[i] ^ (KK << 5)));
     };
     // pre-activation BN + ReLU of a pixel fragment (fp16 FMA, one rounding: resnet_v2.py:119)
     auto act_b = [&](auto kk_c, int j) {
@@ -203,60 +224,52 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
         }
 #endif
     };
-    // four MFMAs (cout tile i against the four pixel tiles) on fragment set KK
-    auto mma4 = [&](auto kk_c, int i) {
+    // NJ MFMAs (cout tile i against the wave's pixel tiles) on fragment set KK
+    auto mma_row = [&](auto kk_c, int i) {
         constexpr int KK = decltype(kk_c)::value;
 #ifndef METRO_DBG_G4D_NO_MFMA
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[KK][i], bf[KK][j], acc[i][j], 0, 0, 0);
 #else
-        const half8_t a_ = af[KK][i], b0_ = bf[KK][0], b1_ = bf[KK][1], b2_ = bf[KK][2], b3_ = bf[KK][3];
-        asm volatile("" ::"v"(a_), "v"(b0_), "v"(b1_), "v"(b2_), "v"(b3_));
+        const half8_t a_ = af[KK][i], b0_ = bf[KK][0], b1_ = bf[KK][NJ - 1];
+        asm volatile("" ::"v"(a_), "v"(b0_), "v"(b1_));
 #endif
     };
-    // emitted order of a four-MFMA segment: behind MFMA m, r[m] LDS reads, then v VALU ops
-    auto pin4 = [&](int r0, int r1, int r2, int r3, int v) {
-        const int r[4] = {r0, r1, r2, r3};
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (r[m] == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (r[m] == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            if (PROLOGUE && v == 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            if (PROLOGUE && v == 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        }
-    };
-    // One k step: 16 MFMAs on set KK; set KK + 1 pre-activated (32 VALU ops, two behind every MFMA); set KK + 2 read from buffer RB
-    // (table rows of K tile kr).  dma(e): request e of this k step's share (or nothing).  Memory operations do not cross an asm
-    // volatile statement: reads and requests stay in the four-MFMA segment they are written in.
+    // One k step: MI segments of NJ MFMAs on set KK; in segment i the cout fragment i and NJ / MI pixel fragments of set KK + 2 are
+    // read from buffer RB (table rows of K tile kr) and NJ / MI pixel fragments of set KK + 1 are pre-activated; two request slots
+    // behind every segment (dma(e): request slot e of this k step, or nothing).  Memory operations do not cross an asm volatile
+    // statement: reads and requests stay in the segment they are written in; the emitted order inside a segment is pinned.
+    constexpr int BPS = NJ / MI > 0 ? NJ / MI : 1;          // pixel fragments read / pre-activated per segment
     auto kstep = [&](auto kk_c, auto rbuf_c, int kr, auto dma) {
         constexpr int KK = decltype(kk_c)::value;
         using S = std::integral_constant<int, KK>;
         using V = std::integral_constant<int, (KK + 1) & 3>;
         using R = std::integral_constant<int, (KK + 2) & 3>;
         using RB = decltype(rbuf_c);
-        read_pro(R{}, kr);
-        read_b(RB{}, R{}, 0); read_b(RB{}, R{}, 1);
-        act_b(V{}, 0);
-        mma4(S{}, 0);
-        pin4(PROLOGUE ? 2 : 1, PROLOGUE ? 2 : 1, 0, 0, 2);
-        dma(I0{}); dma(I1{});
-        read_b(RB{}, R{}, 2); read_b(RB{}, R{}, 3);
-        act_b(V{}, 1);
-        mma4(S{}, 1);
-        pin4(1, 1, 0, 0, 2);
-        dma(I2{}); dma(I3{});
-        read_a(RB{}, R{}, 0); read_a(RB{}, R{}, 1);
-        act_b(V{}, 2);
-        mma4(S{}, 2);
-        pin4(1, 1, 0, 0, 2);
-        dma(I4{}); dma(I5{});
-        read_a(RB{}, R{}, 2); read_a(RB{}, R{}, 3);
-        act_b(V{}, 3);
-        mma4(S{}, 3);
-        pin4(1, 1, 0, 0, 2);
-        dma(I6{}); dma(I7{});
+        g4d_for<MI>([&](auto i_c) {
+            constexpr int I = decltype(i_c)::value;
+            if constexpr (I == 0) read_pro(R{}, kr);
+#pragma unroll
+            for (int b = 0; b < BPS; ++b)
+                if (I * BPS + b < NJ) { read_b(RB{}, R{}, I * BPS + b); act_b(V{}, I * BPS + b); }
+            read_a(RB{}, R{}, I);
+            mma_row(S{}, I);
+            constexpr int NREAD = BPS + 1 + ((I == 0 && PROLOGUE) ? 2 : 0);
+            constexpr int NVALU = 8 * BPS;
+#pragma unroll
+            for (int m = 0; m < NJ; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (m * ((NREAD + NJ - 1) / NJ) < NREAD) {
+                    if constexpr ((NREAD + NJ - 1) / NJ == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                if constexpr (PROLOGUE && NVALU / NJ == 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                if constexpr (PROLOGUE && NVALU / NJ == 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+            dma(std::integral_constant<int, 2 * I>{});
+            dma(std::integral_constant<int, 2 * I + 1>{});
+        });
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -264,16 +277,15 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
     read_pro(I0{}, 0);
     read_pro(I1{}, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { read_b(I0{}, I0{}, j); read_b(I0{}, I1{}, j); }
+    for (int j = 0; j < NJ; ++j) { read_b(I0{}, I0{}, j); read_b(I0{}, I1{}, j); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { read_a(I0{}, I0{}, i); read_a(I0{}, I1{}, i); }
+    for (int i = 0; i < MI; ++i) { read_a(I0{}, I0{}, i); read_a(I0{}, I1{}, i); }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) act_b(I0{}, j);
+    for (int j = 0; j < NJ; ++j) act_b(I0{}, j);
 
     // One K tile (BUF = kt % 2: the loop is unrolled by two).  Requests past the end re-request the LAST tile (valid memory, a
-    // buffer nobody reads any more) so that the body and its waits are the same for every tile.
-    //   requests of tile kt + 2 -> this buffer (retired at the barrier): k step 2: pixel rows e = 0..5; k step 3: pixel rows 6, 7 and
-    //   cout rows 0..3; k step 0 of the NEXT tile: cout rows 4..7 (weights are L2 resident: the short lead is theirs)
+    // buffer nobody reads any more) so that the body and its waits are the same for every tile.  The R requests of tile kt + 2 go
+    // into this buffer (retired at the barrier) in three shares: Q in k step 2, Q in k step 3, the rest in k step 0 of the next tile.
     auto ktile = [&](auto buf_c, int kt) {
         constexpr int BUF = decltype(buf_c)::value;
         using B = std::integral_constant<int, BUF>;
@@ -282,9 +294,7 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
         const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;
         kstep(I0{}, B{}, kt, [&](auto e_c) {
             constexpr int E = decltype(e_c)::value;
-#ifndef METRO_DBG_G4D_NO_DMA
-            if constexpr (E % 2 == 0) req_a(N{}, std::integral_constant<int, 4 + E / 2>{}, k1);
-#endif
+            if constexpr (2 * G::Q + E < G::R) req(N{}, std::integral_constant<int, 2 * G::Q + E>{}, k1);
         });
         kstep(I1{}, B{}, kt, [&](auto) {});
         // every read of this buffer retired, tile kt + 1 landed (this wave's share; the barrier makes it everybody's)
@@ -295,16 +305,11 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
 #endif
         kstep(I2{}, N{}, k1, [&](auto e_c) {
             constexpr int E = decltype(e_c)::value;
-#ifndef METRO_DBG_G4D_NO_DMA
-            if constexpr (E < 6) req_b(B{}, e_c, k2);
-#endif
+            if constexpr (E < G::Q && E < G::R) req(B{}, e_c, k2);
         });
         kstep(I3{}, N{}, k1, [&](auto e_c) {
             constexpr int E = decltype(e_c)::value;
-#ifndef METRO_DBG_G4D_NO_DMA
-            if constexpr (E < 2) req_b(B{}, std::integral_constant<int, 6 + E>{}, k2);
-            else if constexpr (E < 6) req_a(B{}, std::integral_constant<int, E - 2>{}, k2);
-#endif
+            if constexpr (E < G::Q && G::Q + E < G::R) req(B{}, std::integral_constant<int, G::Q + E>{}, k2);
         });
     };
     for (int t = 0; t < nk; t += 2) {
@@ -321,14 +326,14 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
     const int o_relu = second ? a.relu2 : a.relu;
     half_t* o_ptr = second ? out2 : out;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int col = wr * 128 + i * 32 + 8 * q + 4 * frag_half;
+            const int col = wr * (TM / 2) + i * 32 + 8 * q + 4 * frag_half;
             const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + n0 + col);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int prow = wc * 128 + j * 32 + frag_row;
+            for (int j = 0; j < NJ; ++j) {
+                const int prow = wc * (TN / 2) + j * 32 + frag_row;
                 half4_t hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -336,13 +341,13 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
                     if (o_relu) v = fmaxf(v, 0.f);
                     hv[e] = (half_t)v;
                 }
-                *reinterpret_cast<half4_t*>(smem + prow * OUT_ROW_BYTES + col * 2) = hv;
+                *reinterpret_cast<half4_t*>(smem + prow * G::OUT_ROW_BYTES + col * 2) = hv;
             }
         }
     }
     __syncthreads();
     constexpr int CPRO = TM / 8;                       // 16-byte chunks per tile row
-    constexpr int EPI_ITERS = TN * CPRO / NT;          // 32
+    constexpr int EPI_ITERS = TN * CPRO / NT;
     const bool res_same = a.res_stride == 1 && a.res_offset == 0 && a.res_h == a.h_out && a.res_w == a.w_out;
     const int hw_out = a.h_out * a.w_out;
 #pragma unroll 4
@@ -352,8 +357,8 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
         const int ch = idx - prow * CPRO;
         const int m = m0 + prow;
         const int co = o_n0 + ch * 8;
-        if (co + 8 > o_c) continue;                    // narrow second output of a fused pair (c_out2 < 256)
-        uint4 v = *reinterpret_cast<const uint4*>(smem + prow * OUT_ROW_BYTES + ch * 16);
+        if (co + 8 > o_c) continue;                    // narrow second output of a fused pair
+        uint4 v = *reinterpret_cast<const uint4*>(smem + prow * G::OUT_ROW_BYTES + ch * 16);
         if (residual != nullptr) {
             size_t rp = m;
             if (!res_same) {
@@ -373,14 +378,55 @@ __global__ __launch_bounds__(g4d::NT) void conv_gemm4d_kernel(
     }
 }
 
-// same shapes as conv_gemm8p (whole 256 x 256 tiles, c_in a multiple of 128: the ring is walked four 32-channel steps at a time)
-bool conv_gemm4d_shape_ok(const MetroConvDesc& d, const ConvSplit* split) { return conv_gemm8p_shape_ok(d, split); }
+// What a tile geometry can run: 1x1, stride 1, dense NHWC fp16 in / out, c_in a multiple of 128 (two 64-channel K tiles per loop
+// iteration), whole tiles of 64 MI couts x 64 NJ pixels; fused pairs split on a tile boundary with a 256-channel second output
+template <int MI, int NJ>
+static bool g4d_shape_ok(const MetroConvDesc& d, const ConvSplit* split) {
+    if (!(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_top == 0 && d.pad_left == 0 && d.in_pix_stride == d.c_in &&
+          d.h_in == d.h_out && d.w_in == d.w_out && d.in_dtype == METRO_F16 && d.out_dtype == METRO_F16))
+        return false;
+    const long m = (long)d.n * d.h_out * d.w_out;
+    if (d.c_in % 128 != 0 || d.c_in < 128 || d.c_in > 2048 || d.c_out % (64 * MI) != 0 || m % (64 * NJ) != 0) return false;
+    if (split != nullptr && split->split > 0 && (split->split % (64 * MI) != 0 || split->c_out2 != 256 || d.has_residual)) return false;
+    return true;
+}
+bool conv_gemm4d_shape_ok(const MetroConvDesc& d, const ConvSplit* split) { return g4d_shape_ok<4, 4>(d, split); }
+// tile geometry ids: 0 = 256 x 256 (4 x 4 tiles per wave), 1 = 128 couts x 128 pixels (2 x 2, two blocks per CU), 2 = 128 couts x 256 pixels
+bool conv_gemm4d_geo_ok(const MetroConvDesc& d, const ConvSplit* split, int geo) {
+    return geo == 0 ? g4d_shape_ok<4, 4>(d, split) : geo == 1 ? g4d_shape_ok<2, 2>(d, split) : geo == 2 ? g4d_shape_ok<2, 4>(d, split) : false;
+}
+
+template <int MI, int NJ>
+static int g4d_launch(const MetroConvDesc& d, const ConvArgs& a, const void* in, const void* w, const float* bias, const void* ps,
+                      const void* pb, const half_t* r, void* out, void* out2, hipStream_t stream) {
+    using G = g4d::Geo<MI, NJ>;
+    const int tiles_m = (d.c_out + G::TM - 1) / G::TM;
+    const int tiles_n = (a.m_total + G::TN - 1) / G::TN;
+    if (d.has_prologue) {
+        auto kern = conv_gemm4d_kernel<true, MI, NJ>;
+        constexpr int lds = G::MAIN_BYTES + g4d::PRO_BYTES;
+        static PerDeviceInt done;
+        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4d<pro>")) return st;
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(g4d::NT), lds, stream, a, static_cast<const half_t*>(in),
+                           static_cast<const half_t*>(w), bias, static_cast<const half_t*>(ps), static_cast<const half_t*>(pb), r,
+                           static_cast<half_t*>(out), static_cast<half_t*>(out2), tiles_m);
+    } else {
+        auto kern = conv_gemm4d_kernel<false, MI, NJ>;
+        constexpr int lds = G::MAIN_BYTES;
+        static PerDeviceInt done;
+        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4d")) return st;
+        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(g4d::NT), lds, stream, a, static_cast<const half_t*>(in),
+                           static_cast<const half_t*>(w), bias, nullptr, nullptr, r, static_cast<half_t*>(out),
+                           static_cast<half_t*>(out2), tiles_m);
+    }
+    return launch_status("conv_gemm4d");
+}
 
 int launch_conv_gemm4d(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* ps,
-                       const void* pb, const void* res, void* out, hipStream_t stream, const ConvSplit* split) {
-    if (!conv_gemm4d_shape_ok(d, split)) {
-        set_error("conv_gemm4d: needs a 1x1 stride-1 fp16 layer with c_in %% 128 == 0 (<= 2048), c_out %% 256 == 0 and pixels %% 256 == 0 "
-                  "(got c_in %d, c_out %d, %d x %d x %d pixels)", d.c_in, d.c_out, d.n, d.h_out, d.w_out);
+                       const void* pb, const void* res, void* out, hipStream_t stream, const ConvSplit* split, int geo) {
+    if (!conv_gemm4d_geo_ok(d, split, geo)) {
+        set_error("conv_gemm4d: needs a 1x1 stride-1 fp16 layer with c_in %% 128 == 0 (<= 2048) and whole tiles of geometry %d "
+                  "(got c_in %d, c_out %d, %d x %d x %d pixels)", geo, d.c_in, d.c_out, d.n, d.h_out, d.w_out);
         return METRO_ERR_UNSUPPORTED;
     }
     ConvArgs a = make_conv_args(d);
@@ -389,29 +435,13 @@ int launch_conv_gemm4d(const MetroConvDesc& d, const void* in, const void* w, co
         a.split = split->split; a.c_out2 = split->c_out2; a.relu2 = split->relu2;
         out2 = split->out2;
     }
-    if (note_kernel("conv_gemm4d<256x256%s>%s%s", d.has_prologue ? ",pro" : "", d.has_residual ? "+res" : "", a.split > 0 ? "+pair" : ""))
+    static const char* const names[3] = {"256x256", "128x128", "128x256"};
+    if (note_kernel("conv_gemm4d<%s%s>%s%s", names[geo], d.has_prologue ? ",pro" : "", d.has_residual ? "+res" : "", a.split > 0 ? "+pair" : ""))
         return METRO_OK;
-    const int tiles_m = (d.c_out + g4d::TM - 1) / g4d::TM;
-    const int tiles_n = (a.m_total + g4d::TN - 1) / g4d::TN;
     const half_t* r = d.has_residual ? static_cast<const half_t*>(res) : nullptr;
-    if (d.has_prologue) {
-        auto kern = conv_gemm4d_kernel<true>;
-        constexpr int lds = g4d::MAIN_BYTES + g4d::PRO_BYTES;
-        static PerDeviceInt done;
-        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4d<pro>")) return st;
-        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(g4d::NT), lds, stream, a, static_cast<const half_t*>(in),
-                           static_cast<const half_t*>(w), bias, static_cast<const half_t*>(ps), static_cast<const half_t*>(pb), r,
-                           static_cast<half_t*>(out), static_cast<half_t*>(out2), tiles_m);
-    } else {
-        auto kern = conv_gemm4d_kernel<false>;
-        constexpr int lds = g4d::MAIN_BYTES;
-        static PerDeviceInt done;
-        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4d")) return st;
-        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(g4d::NT), lds, stream, a, static_cast<const half_t*>(in),
-                           static_cast<const half_t*>(w), bias, nullptr, nullptr, r, static_cast<half_t*>(out),
-                           static_cast<half_t*>(out2), tiles_m);
-    }
-    return launch_status("conv_gemm4d");
+    if (geo == 0) return g4d_launch<4, 4>(d, a, in, w, bias, ps, pb, r, out, out2, stream);
+    if (geo == 1) return g4d_launch<2, 2>(d, a, in, w, bias, ps, pb, r, out, out2, stream);
+    return g4d_launch<2, 4>(d, a, in, w, bias, ps, pb, r, out, out2, stream);
 }
 
 }  // namespace metro

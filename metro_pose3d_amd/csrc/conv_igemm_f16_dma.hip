@@ -711,6 +711,15 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
         if (four && d.has_prologue) return launch_conv_gemm4w(d, in_, w_, bias, ps_, pb_, res_, out, stream, split);
         return launch_conv_gemm8p(d, in_, w_, bias, ps_, pb_, res_, out, stream, split);
     }
+    {
+        // the LDS-DMA + four-deep-fragment kernel on SMALLER block tiles, for deep-K pre-activated layers whose grid is too small
+        // for 256 x 256 tiles (block3 / block4 conv1 at batch 64): 1 = 128 x 128, 2 = 128 couts x 256 pixels
+        static const int geo = env_int("METRO_G4D_GEO", 0);
+        static const int geo_min_k = env_int("METRO_G4D_GEO_MIN_K", 1024);
+        if (geo > 0 && !(fuse2 != nullptr && fuse2->w2 != nullptr) && d.has_prologue && d.c_in >= geo_min_k &&
+            conv_gemm4d_geo_ok(d, split, geo))
+            return launch_conv_gemm4d(d, in_, w_, bias, ps_, pb_, res_, out, stream, split, geo);
+    }
     if (fuse2 != nullptr && fuse2->w2 != nullptr) {
         if (!conv_f16_fuse2_supported(d, fuse2->c2)) { set_error("conv fuse2: unsupported layer shape (c_out %d c2 %d k %dx%d c_in %d pix_stride %d stride %d pad %d,%d pro %d dt %d/%d hw %dx%d -> %dx%d)",
                                                                  d.c_out, fuse2->c2, d.kh, d.kw, d.c_in, d.in_pix_stride, d.stride, d.pad_top, d.pad_left, d.has_prologue,

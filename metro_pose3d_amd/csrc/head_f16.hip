@@ -238,6 +238,83 @@ __global__ __launch_bounds__(hd::NT) void head_f16_kernel(HeadArgs a) {
     }
 }
 
+// Per-joint softmax statistics of a [32 pixels][LROW] fp32 logits tile, for the 32 lanes of a wave half (lane = pixel; `row` = the
+// lane's tile row): joints j0, j0 + js, ... of the tile.  Exact two-pass softmax over the tile's 32 x D voxels; the 32 lanes fold
+// with xor butterflies 16 .. 1 (ds_swizzle: no address arithmetic, never crossing halves).  Depth 8 (every BASELINE config): the
+// D logits of FIVE joints are read at once and their five reductions run side by side -- the serial form (a dependent LDS read per
+// depth, a dependent shuffle per fold step, one joint at a time) cost 17 of the 69 us of the 256-pixel head.
+template <int O>
+__device__ __forceinline__ float hd_xor32(float v) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (O << 10) | 0x1F));
+}
+template <typename F>
+__device__ __forceinline__ void hd_tile_stats(const float* row, int J, int D, int j0, int js, float cx, float cy, float step_d,
+                                              bool writer, F&& record) {
+    constexpr int NJ = 5;
+    if (D == 8) {
+        for (int jb = j0; jb < J; jb += NJ * js) {
+            float v[NJ][8], m[NJ], s[NJ], sx[NJ], sy[NJ], sz[NJ];
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) {
+                const int j = jb + q * js < J ? jb + q * js : jb;         // past the last joint: joint jb again (not recorded)
+#pragma unroll
+                for (int d = 0; d < 8; ++d) v[q][d] = row[d * J + j];
+            }
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) {
+                m[q] = -INFINITY;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) m[q] = fmaxf(m[q], v[q][d]);
+            }
+#define HD_FOLD_MAX(O)                                                        \
+    _Pragma("unroll") for (int q = 0; q < NJ; ++q) m[q] = fmaxf(m[q], hd_xor32<O>(m[q]))
+            HD_FOLD_MAX(16); HD_FOLD_MAX(8); HD_FOLD_MAX(4); HD_FOLD_MAX(2); HD_FOLD_MAX(1);
+#undef HD_FOLD_MAX
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) {
+                s[q] = 0.f; sz[q] = 0.f;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    const float e = __expf(v[q][d] - m[q]);
+                    s[q] += e;
+                    sz[q] += e * ((float)d * step_d);
+                }
+                sx[q] = s[q] * cx; sy[q] = s[q] * cy;                     // the pixel's coordinates are the lane's
+            }
+#define HD_FOLD_SUM(O)                                                        \
+    _Pragma("unroll") for (int q = 0; q < NJ; ++q) {                          \
+        s[q] += hd_xor32<O>(s[q]); sx[q] += hd_xor32<O>(sx[q]);               \
+        sy[q] += hd_xor32<O>(sy[q]); sz[q] += hd_xor32<O>(sz[q]);             \
+    }
+            HD_FOLD_SUM(16); HD_FOLD_SUM(8); HD_FOLD_SUM(4); HD_FOLD_SUM(2); HD_FOLD_SUM(1);
+#undef HD_FOLD_SUM
+            if (writer) {
+#pragma unroll
+                for (int q = 0; q < NJ; ++q)
+                    if (jb + q * js < J) record(jb + q * js, m[q], s[q], sx[q], sy[q], sz[q]);
+            }
+        }
+        return;
+    }
+    for (int j = j0; j < J; j += js) {
+        float m = -INFINITY;
+        for (int d = 0; d < D; ++d) m = fmaxf(m, row[d * J + j]);
+        m = fmaxf(m, hd_xor32<16>(m)); m = fmaxf(m, hd_xor32<8>(m)); m = fmaxf(m, hd_xor32<4>(m));
+        m = fmaxf(m, hd_xor32<2>(m)); m = fmaxf(m, hd_xor32<1>(m));
+        float s = 0.f, sz = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float e = __expf(row[d * J + j] - m);
+            s += e;
+            sz += e * ((float)d * step_d);
+        }
+        float sx = s * cx, sy = s * cy;
+#define HD_FOLD1(O) s += hd_xor32<O>(s); sx += hd_xor32<O>(sx); sy += hd_xor32<O>(sy); sz += hd_xor32<O>(sz)
+        HD_FOLD1(16); HD_FOLD1(8); HD_FOLD1(4); HD_FOLD1(2); HD_FOLD1(1);
+#undef HD_FOLD1
+        if (writer) record(j, m, s, sx, sy, sz);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The same head with 256-PIXEL tiles, for heads with at least one such tile per CU (RN50-s4 at 16 crops, the stride-16 nets
 // from 256 crops on).  A 64-pixel tile re-streams the head's 557 KB of weights for 0.14 GFLOP (44 FLOP/B through the L2 -> LDS
@@ -408,32 +485,286 @@ __global__ __launch_bounds__(hd2::NT) void head_f16_kernel256(HeadArgs a) {
             const int py = pim / a.side, px = pim - py * a.side;
             const float cx = (float)px * step_s, cy = (float)py * step_s;
             const int slab = tile * (TN / 32) + wave;
-            for (int j = frag_half; j < a.J; j += 2) {
-                float m = -INFINITY;
-                for (int d = 0; d < a.D; ++d) m = fmaxf(m, lt[frag_row * LROW + d * a.J + j]);
-#pragma unroll
-                for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-                float s = 0.f, sz = 0.f;
-                for (int d = 0; d < a.D; ++d) {
-                    const float e = __expf(lt[frag_row * LROW + d * a.J + j] - m);
-                    s += e;
-                    sz += e * ((float)d * step_d);
-                }
-                float sx = s * cx, sy = s * cy;
-#pragma unroll
-                for (int o = 16; o >= 1; o >>= 1) {
-                    s += __shfl_xor(s, o, 64);
-                    sx += __shfl_xor(sx, o, 64);
-                    sy += __shfl_xor(sy, o, 64);
-                    sz += __shfl_xor(sz, o, 64);
-                }
-                if (frag_row == 0) {
-                    float* o5 = a.partials + (((size_t)img * a.slabs + slab) * a.J + j) * 5;
-                    o5[0] = m; o5[1] = s; o5[2] = sx; o5[3] = sy; o5[4] = sz;
-                }
-            }
+            float* rec = a.partials + ((size_t)img * a.slabs + slab) * a.J * 5;
+            hd_tile_stats(lt + frag_row * LROW, a.J, a.D, frag_half, 2, cx, cy, step_d, frag_row == 0,
+                          [&](int j, float m, float s_, float sx, float sy, float sz) {
+                              float* o5 = rec + j * 5;
+                              o5[0] = m; o5[1] = s_; o5[2] = sx; o5[3] = sy; o5[4] = sz;
+                          });
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the 256-pixel head for heads of at most 144 channels (17 joints x depth 8), K steps of 64 channels.
+// What the kernel above is bound by: (1) its 32-channel K steps are 64-byte row pieces -- the L2s answer a
+// roughly constant REQUEST rate, half-line requests halve the bytes (8.7 against 13.8 TB/s); (2) a wave tile of 160 channels x 32
+// pixels reads 7 KB of fragments per 5 MFMAs: 8 waves x 64 k-steps x 2 = 8.4 MB of LDS reads per block = 27 us at 128 B/clk, more
+// than its 17 us of MFMAs; (3) 64 barriers with dependent fragment reads behind each.  Here:
+//   * K steps of 64 channels in 128-byte row pieces, three 50 KiB stages (144 weight rows -- the accumulator rows past them read
+//     into the pixel rows: channels nobody looks at -- + 256 pixel rows), two steps (100 KiB) in flight, 32 barriers;
+//   * 8 waves = 4 pixel groups of 64 x 2 K-halves of every step (k-steps 2h, 2h + 1): a wave tile of 160 x 64 reads 7 KB per
+//     TEN MFMAs (LDS 896 of the 1 280 MFMA cycles of a step), two waves per SIMD hide each other's fragment latency;
+//   * the two K-halves are added through the wave pair's LDS tile in a fixed order (h = 1 writes, h = 0 adds and adds the bias),
+//     32 pixels at a time; the pair shares the per-joint statistics of the tile (joints 2h + lane half, step 4).
+// The same records as the kernel above: one per (image, 32-pixel slab, joint).
+namespace hd3 {
+constexpr int WROWS = 144, MT = 5, TN = 256, BK = 64, NW = 8, NT = 512, STAGES = 3;
+constexpr int ROW_BYTES = BK * 2;                      // 128
+constexpr int STAGE_BYTES = (WROWS + TN) * ROW_BYTES;  // 50 KiB
+constexpr int RING_BYTES = STAGES * STAGE_BYTES;       // 150 KiB
+constexpr int LROW = 161;
+constexpr int WTILE_BYTES = 4 * 32 * LROW * 4;         // four pair-private [32][161] fp32 tiles
+constexpr int PRO_OFF = RING_BYTES;
+constexpr int BIAS_OFF = PRO_OFF + 2 * 2048 * 2;       // 256 fp32 bias words (one LDS-DMA instruction)
+constexpr int LDS_BYTES = BIAS_OFF + 1024;             // 159 KiB
+constexpr int GA = WROWS / 8, GB = TN / 8;             // DMA instructions (8 rows x 128 B) per K step: 18 weight + 32 pixel groups
+static_assert(LDS_BYTES <= 160 * 1024 && WTILE_BYTES <= RING_BYTES && GA <= 3 * NW && GB == 4 * NW, "LDS / loader split");
+}  // namespace hd3
+
+// one LDS-DMA wave-instruction, source = wave-uniform base + per-lane byte offset, destination (lds_base + LDS_IMM) + 16 l
+template <int LDS_IMM>
+__device__ __forceinline__ void hd_dma16s(const void* sbase, unsigned voff, unsigned lds_base) {
+    asm volatile(
+        "s_add_u32 m0, %2, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(sbase), "s"(lds_base), "n"(LDS_IMM)
+        : "scc");
+}
+
+__global__ __launch_bounds__(hd3::NT, 2) void head_f16_kernel256h(HeadArgs a) {
+    using namespace hd3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wave >> 1, h = wave & 1;       // 64-pixel group, K-half of every step (a pair shares an LDS logits tile)
+    const int tile = blockIdx.x, img = blockIdx.y;
+    const int m0 = img * a.pixels + tile * TN;
+    const int K = a.K, nk = K / BK;
+    const unsigned smem_base = (unsigned)(size_t)(hd_lds_void_t*)smem;
+    half_t* pro_lds = reinterpret_cast<half_t*>(smem + PRO_OFF);
+
+    // ---- DMA sources per K step (one instruction = 8 rows x 128 B, lane: row l >> 3, physical chunk l & 7): pixel groups
+    //      wave + 8 i (four each), weight groups wave, wave + 8, wave + 16 (< 18: waves 0-1 issue three, the others two).  Rows past
+    //      the head's channels repeat its last row (channels nobody looks at).
+    const int lrow = lane >> 3, lch = lane & 7;
+    const int na = wave < GA - 2 * NW ? 3 : 2;
+    unsigned voffw[3], voffx[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int row = (wave + NW * i) * 8 + lrow;
+        const int srow = row < a.C ? row : a.C - 1;
+        voffw[i] = (unsigned)(srow * K + ((lch ^ hd_swz(row)) * 8)) * 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int prow = (wave + NW * i) * 8 + lrow;
+        voffx[i] = (unsigned)(prow * K + ((lch ^ hd_swz(prow)) * 8)) * 2u;
+    }
+    const half_t* xbase = a.x + (size_t)m0 * K;
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane(smem_base + wave * 8 * ROW_BYTES);
+    auto issue_step = [&](int slot_off, int kt) {       // K step kt into the stage at byte offset slot_off
+        const unsigned base = lds_wave + slot_off;
+        const half_t* xs = xbase + kt * BK;
+        const half_t* ws = a.w + kt * BK;
+#ifndef METRO_DBG_HD3_NO_X
+        hd_dma16s<WROWS * ROW_BYTES + 0 * NW * 8 * ROW_BYTES>(xs, voffx[0], base);      // the pixel rows first: first touch from HBM
+        hd_dma16s<WROWS * ROW_BYTES + 1 * NW * 8 * ROW_BYTES>(xs, voffx[1], base);
+        hd_dma16s<WROWS * ROW_BYTES + 2 * NW * 8 * ROW_BYTES>(xs, voffx[2], base);
+        hd_dma16s<WROWS * ROW_BYTES + 3 * NW * 8 * ROW_BYTES>(xs, voffx[3], base);
+#endif
+#ifndef METRO_DBG_HD3_NO_W
+        hd_dma16s<0 * NW * 8 * ROW_BYTES>(ws, voffw[0], base);
+        hd_dma16s<1 * NW * 8 * ROW_BYTES>(ws, voffw[1], base);
+        if (na == 3) hd_dma16s<2 * NW * 8 * ROW_BYTES>(ws, voffw[2], base);
+#endif
+    };
+
+    floatx16 acc[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][i][e] = 0.f;
+    const int frag_row = lane & 31, frag_half = lane >> 5;
+
+    // ---- prologue: the postnorm table by LDS-DMA FIRST (the oldest requests: every counted wait below covers them; waves 0-3 a
+    //      KiB of the scale each, waves 4-7 of the shift), then all three stages; stage 0 landed ----
+    {
+        const int idx = (wave & 3) * 512 + lane * 8;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + PRO_OFF + (wave >> 2) * 4096 + (wave & 3) * 1024);
+        hd_dma16s<0>(wave < 4 ? a.pro_scale : a.pro_shift, (unsigned)((idx < K ? idx : 0) * 2), dst);
+        // ... and the bias (a global load in the statistics phase costs a memory latency per use)
+        hd_dma16s<0>(a.bias, (unsigned)((lane * 4 < a.C ? lane * 4 : 0) * 4), smem_base + BIAS_OFF);
+    }
+    issue_step(0, 0);
+    issue_step(STAGE_BYTES, nk > 1 ? 1 : 0);
+    issue_step(2 * STAGE_BYTES, nk > 2 ? 2 : nk - 1);
+#if defined(METRO_DBG_HD3_NO_X) || defined(METRO_DBG_HD3_NO_W)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    if (na == 3) asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+#endif
+    const float* bias_lds = reinterpret_cast<const float*>(smem + BIAS_OFF);
+
+    // fragment addresses inside a stage, per k-step of the wave's K-half (kq = 0, 1: the 16-byte chunk (2 h + kq) 2 + lane half)
+    unsigned a_addr[2][MT], b_addr[2][2];
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+        const int chunk = (h * 2 + kq) * 2 + frag_half;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = i * 32 + frag_row;
+            a_addr[kq][i] = row * ROW_BYTES + ((chunk ^ hd_swz(row)) << 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int brow = pg * 64 + t * 32 + frag_row;
+            b_addr[kq][t] = WROWS * ROW_BYTES + brow * ROW_BYTES + ((chunk ^ hd_swz(brow)) << 4);
+        }
+    }
+    // A wave's work is a chain of PHASES (K step k, kq): ten MFMAs = five weight fragments against its two pixel fragments.  The
+    // weight fragments are read TWO MFMA pairs ahead of their use (af[parity of the phase][tile]: the last two pairs of a phase read
+    // the first two fragments of the next), the pixel fragments and table rows of the next phase during the first pairs of this one
+    // (pre-activated before the phase ends): no MFMA waits for an LDS read of its own pair.
+    half8_t af[2][MT], bq[2][2], braw[2], sc = {}, sh = {};
+    auto rd_a = [&](auto par_c, auto i_c, int soff, auto kq_c) {
+        af[decltype(par_c)::value][decltype(i_c)::value] =
+            *reinterpret_cast<const half8_t*>(smem + soff + a_addr[decltype(kq_c)::value][decltype(i_c)::value]);
+    };
+    auto rd_b = [&](int soff, int k0, auto kq_c) {       // both raw pixel fragments and the table rows of their 8 channels
+        constexpr int KQ = decltype(kq_c)::value;
+        braw[0] = *reinterpret_cast<const half8_t*>(smem + soff + b_addr[KQ][0]);
+        braw[1] = *reinterpret_cast<const half8_t*>(smem + soff + b_addr[KQ][1]);
+        const int chunk = (h * 2 + KQ) * 2 + frag_half;
+        sc = *reinterpret_cast<const half8_t*>(pro_lds + k0 + chunk * 8);
+        sh = *reinterpret_cast<const half8_t*>(pro_lds + 2048 + k0 + chunk * 8);
+    };
+    auto act = [&](auto par_c, auto t_c) {               // postnorm BN + ReLU, fp16 FMA, one rounding (resnet_v2.py:229)
+        const half8_t z = {};
+        bq[decltype(par_c)::value][decltype(t_c)::value] = __builtin_elementwise_max(braw[decltype(t_c)::value] * sc + sh, z);
+    };
+    auto mma = [&](auto par_c, auto i_c) {
+        constexpr int P = decltype(par_c)::value, I = decltype(i_c)::value;
+#ifndef METRO_DBG_HD3_NO_MFMA
+        acc[0][I] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[P][I], bq[P][0], acc[0][I], 0, 0, 0);
+        acc[1][I] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[P][I], bq[P][1], acc[1][I], 0, 0, 0);
+#else
+        const half8_t a_ = af[P][I], b0_ = bq[P][0], b1_ = bq[P][1];
+        asm volatile("" ::"v"(a_), "v"(b0_), "v"(b1_));
+#endif
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    // the emitted order of a segment: its LDS reads, an MFMA, half of its VALU work, the other MFMA, the rest
+#define HD3_PIN(NREAD, NVALU)                                       \
+    __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);          \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
+    __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);          \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
+    __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);          \
+    __builtin_amdgcn_sched_barrier(0)
+
+    rd_b(0, 0, I0{});
+    rd_a(I0{}, I0{}, 0, I0{});
+    rd_a(I0{}, I1{}, 0, I0{});
+    act(I0{}, I0{});
+    act(I0{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+
+    int cur = 0;                                   // byte offset of the stage of K step k
+    for (int k = 0; k < nk; ++k) {
+        const int nxt = cur + STAGE_BYTES == RING_BYTES ? 0 : cur + STAGE_BYTES;
+        const int k0 = k * BK;
+        const int k1 = k + 1 < nk ? k + 1 : nk - 1;
+        const int k3 = k + 3 < nk ? k + 3 : nk - 1;       // past the end: the last step again (valid memory, a stage nobody reads)
+        // ---- phase (k, 0) ----
+        rd_a(I0{}, I2{}, cur, I0{}); rd_b(cur, k0, I1{}); mma(I0{}, I0{}); HD3_PIN(5, 2);
+        rd_a(I0{}, I3{}, cur, I0{}); mma(I0{}, I1{}); HD3_PIN(1, 2);
+        rd_a(I0{}, I4{}, cur, I0{}); act(I1{}, I0{}); mma(I0{}, I2{}); HD3_PIN(1, 4);
+        rd_a(I1{}, I0{}, cur, I1{}); act(I1{}, I1{}); mma(I0{}, I3{}); HD3_PIN(1, 4);
+        rd_a(I1{}, I1{}, cur, I1{}); mma(I0{}, I4{}); HD3_PIN(1, 2);
+        // ---- phase (k, 1) ----
+        rd_a(I1{}, I2{}, cur, I1{}); mma(I1{}, I0{}); HD3_PIN(1, 2);
+        rd_a(I1{}, I3{}, cur, I1{}); mma(I1{}, I1{}); HD3_PIN(1, 2);
+        rd_a(I1{}, I4{}, cur, I1{}); mma(I1{}, I2{}); HD3_PIN(1, 2);
+        // every read of this stage is complete in every wave and step k + 1 has landed (this wave's share; the barrier makes it
+        // everybody's); step k + 2 stays in flight, step k + 3 goes into this stage
+#if defined(METRO_DBG_HD3_NO_X) || defined(METRO_DBG_HD3_NO_W)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+        if (na == 3) hd_wait_barrier<7>(); else hd_wait_barrier<6>();
+#endif
+        issue_step(cur, k3);
+        rd_a(I0{}, I0{}, nxt, I0{}); rd_b(nxt, k1 * BK, I0{}); mma(I1{}, I3{}); HD3_PIN(5, 2);
+        rd_a(I0{}, I1{}, nxt, I0{}); mma(I1{}, I4{}); HD3_PIN(1, 2);
+        act(I0{}, I0{});
+        act(I0{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+#undef HD3_PIN
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the re-requested tail has landed everywhere: the
+                                                                                 // logits tiles overlay the ring
+
+    // ---- K-halves -> fp32 logits (+ bias) of the pair's 32 pixels, then the per-joint statistics, twice (32 pixels each) ----
+    float* lt = reinterpret_cast<float*>(smem) + pg * (32 * LROW);
+    const float step_s = 1.0f / (float)(a.side - 1);
+    const float step_d = 1.0f / (float)(a.D - 1);
+#ifdef METRO_DBG_HD3_NO_SOFTMAX
+    if (a.J > 0) { float v = 0.f; for (int t = 0; t < 2; ++t) for (int i = 0; i < MT; ++i) v += acc[t][i][t + i]; if (v == 12345.f) a.partials[tid] = v; return; }
+#endif
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (h == 1) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = i * 32 + 8 * q + 4 * frag_half;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lt[frag_row * LROW + c0 + e] = acc[t][i][4 * q + e];
+                }
+        }
+        __syncthreads();
+        if (h == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = i * 32 + 8 * q + 4 * frag_half;
+                    const floatx4 bv = *reinterpret_cast<const floatx4*>(bias_lds + c0);     // words past the head's channels: unused
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)      // (first K-half + second K-half) + bias: a fixed order
+                        lt[frag_row * LROW + c0 + e] = (acc[t][i][4 * q + e] + lt[frag_row * LROW + c0 + e]) + bv[e];
+                }
+        }
+        __syncthreads();
+        const int p0 = pg * 64 + t * 32;                          // first pixel of the tile inside the block
+        if (a.logits_out != nullptr) {
+            for (int idx = h * 64 + lane; idx < 32 * a.C; idx += 128) {
+                const int p = idx / a.C, c = idx - p * a.C;
+                a.logits_out[(size_t)(m0 + p0 + p) * a.C + c] = lt[p * LROW + c];
+            }
+        }
+        const int pim = tile * TN + p0 + frag_row;                // pixel index inside the image
+        const int py = pim / a.side, px = pim - py * a.side;
+        const float cx = (float)px * step_s, cy = (float)py * step_s;
+        const int slab = tile * (TN / 32) + pg * 2 + t;
+        float* rec = a.partials + ((size_t)img * a.slabs + slab) * a.J * 5;
+        hd_tile_stats(lt + frag_row * LROW, a.J, a.D, h * 2 + frag_half, 4, cx, cy, step_d, frag_row == 0,
+                      [&](int j, float m, float s_, float sx, float sy, float sz) {
+                          float* o5 = rec + j * 5;
+                          o5[0] = m; o5[1] = s_; o5[2] = sx; o5[3] = sy; o5[4] = sz;
+                      });
+        __syncthreads();                                          // the tile is rewritten in the next round
     }
 }
 
@@ -462,13 +793,21 @@ int launch_head_f16(const void* x, const void* w, const float* bias, const void*
         return METRO_ERR_UNSUPPORTED;
     }
     const bool big = head_f16_big(n, side);
-    if (note_kernel(big ? "head_f16<160x256>" : "head_f16<160x64>")) return METRO_OK;
+    static const int halves = tuning_knob("METRO_HEAD_256H", 1);
+    const bool bigh = big && halves && c_head <= hd3::WROWS && c_in / hd3::BK >= hd3::STAGES;
+    if (note_kernel(bigh ? "head_f16<144x256,khalves>" : big ? "head_f16<160x256>" : "head_f16<160x64>")) return METRO_OK;
     HeadArgs a;
     a.x = static_cast<const half_t*>(x); a.w = static_cast<const half_t*>(w); a.bias = bias;
     a.pro_scale = static_cast<const half_t*>(pro_scale); a.pro_shift = static_cast<const half_t*>(pro_shift);
     a.partials = partials; a.logits_out = logits_out;
     a.K = c_in; a.C = c_head; a.J = n_joints; a.D = depth; a.side = side; a.pixels = side * side;
     a.slabs = head_f16_records(n, side);
+    if (bigh) {
+        static PerDeviceInt done3;
+        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(head_f16_kernel256h), hd3::LDS_BYTES, done3, "head_f16<256h>")) return st;
+        hipLaunchKernelGGL(head_f16_kernel256h, dim3(side * side / hd3::TN, n), dim3(hd3::NT), hd3::LDS_BYTES, stream, a);
+        return launch_status("head_f16<256h>");
+    }
     if (big) {
         static PerDeviceInt done2;
         if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(head_f16_kernel256), hd2::LDS_BYTES, done2, "head_f16<256>")) return st;

@@ -231,8 +231,11 @@ int launch_conv_gemm4w(const MetroConvDesc& d, const void* in, const void* w, co
                        const void* pro_shift, const void* residual, void* out, hipStream_t stream, const ConvSplit* split);
 // the same GEMM with four waves of 128 x 128 and BOTH operands by LDS-DMA through a ring of four 32-channel slots (conv_gemm4d.hip)
 bool conv_gemm4d_shape_ok(const MetroConvDesc& d, const ConvSplit* split);
+// tile geometry: 0 = 256 couts x 256 pixels, 1 = 128 x 128 (two blocks per CU), 2 = 128 couts x 256 pixels
+bool conv_gemm4d_geo_ok(const MetroConvDesc& d, const ConvSplit* split, int geo);
 int launch_conv_gemm4d(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* pro_scale,
-                       const void* pro_shift, const void* residual, void* out, hipStream_t stream, const ConvSplit* split = nullptr);
+                       const void* pro_shift, const void* residual, void* out, hipStream_t stream, const ConvSplit* split = nullptr,
+                       int geo = 0);
 // persistent pipelined kernel for block1's 64-channel 1x1 convolutions (conv_pw64.hip); mode: 0 plain,
 // 1 projection shortcut + conv1 pair (c_out = 256 + 64 concatenated rows), 2 conv3 + the next unit's conv1
 bool conv_pw64_supported(const MetroConvDesc& d, int mode);

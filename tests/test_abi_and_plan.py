@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/metro_hip.h but not exported'
     assert sorted(_lib.SIGNATURES) == declared, 'bindings and header disagree'
-    assert lib.metro_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.metro_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_ctypes_struct_layout_matches_compiler(tmp_path):

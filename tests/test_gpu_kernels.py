@@ -563,7 +563,7 @@ G8_CASES = [('k128', 2, 128, 256, 'plain'), ('k256_relu', 3, 256, 512, 'relu'), 
 
 
 @pytest.mark.parametrize('case', G8_CASES, ids=[c[0] for c in G8_CASES])
-@pytest.mark.parametrize('kernel', ['gemm8p', 'gemm4w', 'gemm4d'])
+@pytest.mark.parametrize('kernel', ['gemm8p', 'gemm4w', 'gemm4d', 'gemm4d_geo1', 'gemm4d_geo2'])
 def test_conv_gemm8p(lib, cuda, case, kernel):
     """Every element against fp64 on the same fp16 operands: 2e-3 of the layer maximum (fp16 output rounding), for the
     plain / ReLU / pre-activation / shortcut epilogues and the fused shortcut+conv1 pair routing (reference
@@ -591,7 +591,13 @@ def test_conv_gemm8p(lib, cuda, case, kernel):
     out = torch.full((n, 16, 16, c1), float('nan'), dtype=torch.float16, device=cuda)
     out2 = torch.full((n, 16, 16, 256), float('nan'), dtype=torch.float16, device=cuda) if split else None
 
-    entry = getattr(lib, f'metro_conv_f16_{kernel}')         # conv_gemm4w.hip: four waves of 128 x 128, register-staged operands
+    if '_geo' in kernel:                                     # conv_gemm4d.hip on 128 x 128 / 128 x 256 block tiles
+        geo = int(kernel[-1])
+
+        def entry(*args):
+            return lib.metro_conv_f16_gemm4d_geo(*args[:-1], geo, args[-1])
+    else:
+        entry = getattr(lib, f'metro_conv_f16_{kernel}')     # conv_gemm4w.hip: four waves of 128 x 128, register-staged operands
 
     def run():
         check(entry(C.byref(d), H.ptr(tx), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr),

@@ -31,6 +31,7 @@ CONFIGS = {
     'C2-rn50-s16-J17-b64': (ModelSpec(50, 16, 'h36m'), 64),
     'C2-rn50-s16-J17-b256': (ModelSpec(50, 16, 'h36m'), 256),
     'C3-rn50-s16-J19-b64': (ModelSpec(50, 16, 'many19'), 64),
+    'C3-rn50-s16-J19-b256': (ModelSpec(50, 16, 'many19'), 256),       # 152 head channels: the 160 x 256 head (whole K per wave)
     'C4-rn101-s8-J19-b32': (ModelSpec(101, 8, 'many19'), 32),
     'C5-rn50-s4-J17-b16': (ModelSpec(50, 4, 'h36m'), 16),
 }
@@ -74,6 +75,8 @@ def test_every_layer_names_its_kernel_without_a_gpu():
     assert small['block3/unit_2/conv2'] != ids['C4-rn101-s8-J19-b32']['block3/unit_2/conv2']
     # the one-launch head and its finalize
     assert ids['C2-rn50-s16-J17-b64']['logits'] == 'head_f16<160x64>'
+    assert ids['C2-rn50-s16-J17-b256']['logits'] == ids['C5-rn50-s4-J17-b16']['logits'] == 'head_f16<144x256,khalves>'
+    assert ids['C3-rn50-s16-J19-b256']['logits'] == 'head_f16<160x256>'
     assert ids['C2-rn50-s16-J17-b64']['softargmax'] == 'softargmax_finalize<acc32>'
     # parity modes name their kernels too
     e64 = Engine(ModelSpec(50, 16, 'h36m'), None, 'f64', max_batch=2)
@@ -95,7 +98,7 @@ def test_head_partials_slot_covers_large_heat_maps(lib, nb):
     infos = eng.layer_infos()
     logits = next(li for li in infos if li.name == b'logits')
     kern = eng.layer_kernels(nb)[infos.index(logits)]
-    assert kern.startswith('head_f16<160x256') if nb == 8 else kern.startswith('head_f16<') and '160x256' not in kern, kern
+    assert kern == 'head_f16<144x256,khalves>' if nb == 8 else kern.startswith('head_f16<') and 'x256' not in kern, kern
     side, j = 96, spec.skeleton.n_head
     after_logits = logits.out_offset + logits.out_bytes_per_image * nb
     need = lib.metro_head_f16_scratch_bytes(nb, side, j)
