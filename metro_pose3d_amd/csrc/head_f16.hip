@@ -497,31 +497,46 @@ __global__ __launch_bounds__(hd2::NT) void head_f16_kernel256(HeadArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 4: the 256-pixel head for heads of at most 144 channels (17 joints x depth 8), K steps of 64 channels.
-// What the kernel above is bound by: (1) its 32-channel K steps are 64-byte row pieces -- the L2s answer a
+// Round 4: the head in 128-byte row pieces with K-split wave tiles, for every tile width (head_f16_ring_kernel<TN, KSPLIT, WROWS>).
+// What the kernels above are bound by: (1) 32-channel K steps are 64-byte row pieces -- the L2s answer a
 // roughly constant REQUEST rate, half-line requests halve the bytes (8.7 against 13.8 TB/s); (2) a wave tile of 160 channels x 32
-// pixels reads 7 KB of fragments per 5 MFMAs: 8 waves x 64 k-steps x 2 = 8.4 MB of LDS reads per block = 27 us at 128 B/clk, more
-// than its 17 us of MFMAs; (3) 64 barriers with dependent fragment reads behind each.  Here:
-//   * K steps of 64 channels in 128-byte row pieces, three 50 KiB stages (144 weight rows -- the accumulator rows past them read
-//     into the pixel rows: channels nobody looks at -- + 256 pixel rows), two steps (100 KiB) in flight, 32 barriers;
-//   * 8 waves = 4 pixel groups of 64 x 2 K-halves of every step (k-steps 2h, 2h + 1): a wave tile of 160 x 64 reads 7 KB per
-//     TEN MFMAs (LDS 896 of the 1 280 MFMA cycles of a step), two waves per SIMD hide each other's fragment latency;
-//   * the two K-halves are added through the wave pair's LDS tile in a fixed order (h = 1 writes, h = 0 adds and adds the bias),
-//     32 pixels at a time; the pair shares the per-joint statistics of the tile (joints 2h + lane half, step 4).
-// The same records as the kernel above: one per (image, 32-pixel slab, joint).
-namespace hd3 {
-constexpr int WROWS = 144, MT = 5, TN = 256, BK = 64, NW = 8, NT = 512, STAGES = 3;
-constexpr int ROW_BYTES = BK * 2;                      // 128
-constexpr int STAGE_BYTES = (WROWS + TN) * ROW_BYTES;  // 50 KiB
-constexpr int RING_BYTES = STAGES * STAGE_BYTES;       // 150 KiB
-constexpr int LROW = 161;
-constexpr int WTILE_BYTES = 4 * 32 * LROW * 4;         // four pair-private [32][161] fp32 tiles
-constexpr int PRO_OFF = RING_BYTES;
-constexpr int BIAS_OFF = PRO_OFF + 2 * 2048 * 2;       // 256 fp32 bias words (one LDS-DMA instruction)
-constexpr int LDS_BYTES = BIAS_OFF + 1024;             // 159 KiB
-constexpr int GA = WROWS / 8, GB = TN / 8;             // DMA instructions (8 rows x 128 B) per K step: 18 weight + 32 pixel groups
-static_assert(LDS_BYTES <= 160 * 1024 && WTILE_BYTES <= RING_BYTES && GA <= 3 * NW && GB == 4 * NW, "LDS / loader split");
-}  // namespace hd3
+// pixels over the whole K reads 7 KB of fragments per 5 MFMAs: more LDS time than MFMA time; (3) a barrier per step with dependent
+// fragment reads behind it; (4) a serial statistics phase (a dependent LDS read per depth, a dependent shuffle per fold step).  Here:
+//   * K steps of 64 channels in 128-byte row pieces, as many stages as fit 150 KiB (WROWS weight rows -- accumulator rows past
+//     them read into the pixel rows: channels nobody looks at -- + TN pixel rows: 3 x 50 KiB at 256 pixels, 4 x 34-36 at 128,
+//     5 x 26-28 at 64), all but one in flight; the postnorm table and the bias come by LDS-DMA too, ahead of stage 0;
+//   * 8 waves = (8 / KSPLIT) pixel groups x KSPLIT K-parts of EVERY step (part h: k-steps h (4 / KSPLIT) ...): wave tiles of
+//     160 x 64 over two K-halves (256 pixels: 7 KB of fragment reads per TEN MFMAs), 160 x 64 over four K-quarters (128), 160 x 32
+//     over four K-quarters (64);
+//   * weight fragments are read two MFMA groups ahead of their use, pixel fragments and table rows a whole phase ahead; the barrier
+//     of a step sits after the third group of its last phase (every read of the stage is out by then) and the reads of the next
+//     stage follow it: no MFMA waits for an LDS read of its own group;
+//   * the K-parts are added through LDS tiles of the pixel group in a fixed order (((h0 + h1) + h2) + h3) + bias, 32 pixels at a
+//     time; the group's waves share the per-joint statistics of the tile (joints 2 h + lane half, step 2 KSPLIT), five joints at
+//     a time (hd_tile_stats).
+// One record per (image, 32-pixel slab, joint) whatever the tile width.
+template <int TN_, int KSPLIT_, int WROWS_>
+struct HeadRing {
+    static constexpr int TN = TN_, KSPLIT = KSPLIT_, WROWS = WROWS_;
+    static constexpr int MT = 5, BK = 64, NW = 8, NT = 512;
+    static constexpr int PG = NW / KSPLIT;                 // pixel groups
+    static constexpr int PT = TN / 32 / PG;                // 32-pixel tiles per wave
+    static constexpr int NP = 4 / KSPLIT;                  // phases (16-channel k-steps) per wave and K step
+    static constexpr int ROW_BYTES = BK * 2;               // 128
+    static constexpr int STAGE_BYTES = (WROWS + TN) * ROW_BYTES;
+    static constexpr int STAGES = (150 * 1024) / STAGE_BYTES > 5 ? 5 : (150 * 1024) / STAGE_BYTES;
+    static constexpr int RING_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int LROW = 161;
+    static constexpr int WTILE_BYTES = PG * (KSPLIT - 1) * 32 * LROW * 4;    // a group's KSPLIT - 1 [32][161] fp32 tiles
+    static constexpr int PRO_OFF = RING_BYTES;
+    static constexpr int BIAS_OFF = PRO_OFF + 2 * 2048 * 2;                  // 256 fp32 bias words (one LDS-DMA instruction)
+    static constexpr int LDS_BYTES = BIAS_OFF + 1024;
+    static constexpr int GA = WROWS / 8, GB = TN / 8;      // DMA instructions (8 rows x 128 B) per K step
+    static constexpr int NA_HI = (GA + NW - 1) / NW, NA_LO = GA / NW, NA_REM = GA % NW;   // waves < NA_REM issue NA_HI weight groups
+    static constexpr int NB = GB / NW;                     // pixel groups per wave
+    static_assert(PT >= 1 && PT <= 2 && NP >= 1 && STAGES >= 3 && LDS_BYTES <= 160 * 1024 && WTILE_BYTES <= RING_BYTES &&
+                  NA_HI <= 3 && NB >= 1 && NB <= 4 && GB % NW == 0 && WROWS % 8 == 0, "head ring geometry");
+};
 
 // one LDS-DMA wave-instruction, source = wave-uniform base + per-lane byte offset, destination (lds_base + LDS_IMM) + 16 l
 template <int LDS_IMM>
@@ -534,25 +549,41 @@ __device__ __forceinline__ void hd_dma16s(const void* sbase, unsigned voff, unsi
         : "v"(voff), "s"(sbase), "s"(lds_base), "n"(LDS_IMM)
         : "scc");
 }
+// the emitted order of a segment: its LDS reads, then its MFMAs with the VALU work between them
+template <int NREAD, int NMFMA, int NVALU>
+__device__ __forceinline__ void hd_pin() {
+    __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);
+    if constexpr (NMFMA == 2) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
 
-__global__ __launch_bounds__(hd3::NT, 2) void head_f16_kernel256h(HeadArgs a) {
-    using namespace hd3;
+template <int TN_, int KSPLIT_, int WROWS_>
+__global__ __launch_bounds__(512, 2) void head_f16_ring_kernel(HeadArgs a) {
+    using G = HeadRing<TN_, KSPLIT_, WROWS_>;
+    constexpr int TN = G::TN, KSPLIT = G::KSPLIT, WROWS = G::WROWS, MT = G::MT, BK = G::BK, NW = G::NW, PT = G::PT, NP = G::NP;
+    constexpr int ROW_BYTES = G::ROW_BYTES, STAGE_BYTES = G::STAGE_BYTES, STAGES = G::STAGES, RING_BYTES = G::RING_BYTES, LROW = G::LROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pg = wave >> 1, h = wave & 1;       // 64-pixel group, K-half of every step (a pair shares an LDS logits tile)
+    const int pg = wave / KSPLIT, h = wave % KSPLIT;      // pixel group, K-part of every step (the group shares LDS logits tiles)
     const int tile = blockIdx.x, img = blockIdx.y;
     const int m0 = img * a.pixels + tile * TN;
     const int K = a.K, nk = K / BK;
     const unsigned smem_base = (unsigned)(size_t)(hd_lds_void_t*)smem;
-    half_t* pro_lds = reinterpret_cast<half_t*>(smem + PRO_OFF);
+    half_t* pro_lds = reinterpret_cast<half_t*>(smem + G::PRO_OFF);
 
     // ---- DMA sources per K step (one instruction = 8 rows x 128 B, lane: row l >> 3, physical chunk l & 7): pixel groups
-    //      wave + 8 i (four each), weight groups wave, wave + 8, wave + 16 (< 18: waves 0-1 issue three, the others two).  Rows past
-    //      the head's channels repeat its last row (channels nobody looks at).
+    //      wave + 8 i (NB each), weight groups wave + 8 i < GA (the first GA % 8 waves issue one more).  Rows past the head's
+    //      channels repeat its last row (channels nobody looks at).
     const int lrow = lane >> 3, lch = lane & 7;
-    const int na = wave < GA - 2 * NW ? 3 : 2;
+    const bool na_hi = G::NA_REM != 0 && wave < G::NA_REM;
+    const int na = na_hi ? G::NA_HI : G::NA_LO;
     unsigned voffw[3], voffx[4];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -562,7 +593,7 @@ __global__ __launch_bounds__(hd3::NT, 2) void head_f16_kernel256h(HeadArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int prow = (wave + NW * i) * 8 + lrow;
+        const int prow = ((wave + NW * i) * 8 + lrow) & (TN - 1);
         voffx[i] = (unsigned)(prow * K + ((lch ^ hd_swz(prow)) * 8)) * 2u;
     }
     const half_t* xbase = a.x + (size_t)m0 * K;
@@ -572,21 +603,23 @@ __global__ __launch_bounds__(hd3::NT, 2) void head_f16_kernel256h(HeadArgs a) {
         const half_t* xs = xbase + kt * BK;
         const half_t* ws = a.w + kt * BK;
 #ifndef METRO_DBG_HD3_NO_X
-        hd_dma16s<WROWS * ROW_BYTES + 0 * NW * 8 * ROW_BYTES>(xs, voffx[0], base);      // the pixel rows first: first touch from HBM
-        hd_dma16s<WROWS * ROW_BYTES + 1 * NW * 8 * ROW_BYTES>(xs, voffx[1], base);
-        hd_dma16s<WROWS * ROW_BYTES + 2 * NW * 8 * ROW_BYTES>(xs, voffx[2], base);
-        hd_dma16s<WROWS * ROW_BYTES + 3 * NW * 8 * ROW_BYTES>(xs, voffx[3], base);
+        hd_dma16s<WROWS * ROW_BYTES + 0 * 8192>(xs, voffx[0], base);      // the pixel rows first: first touch from HBM
+        if constexpr (G::NB > 1) hd_dma16s<WROWS * ROW_BYTES + 1 * 8192>(xs, voffx[1], base);
+        if constexpr (G::NB > 2) hd_dma16s<WROWS * ROW_BYTES + 2 * 8192>(xs, voffx[2], base);
+        if constexpr (G::NB > 3) hd_dma16s<WROWS * ROW_BYTES + 3 * 8192>(xs, voffx[3], base);
 #endif
 #ifndef METRO_DBG_HD3_NO_W
-        hd_dma16s<0 * NW * 8 * ROW_BYTES>(ws, voffw[0], base);
-        hd_dma16s<1 * NW * 8 * ROW_BYTES>(ws, voffw[1], base);
-        if (na == 3) hd_dma16s<2 * NW * 8 * ROW_BYTES>(ws, voffw[2], base);
+        hd_dma16s<0 * 8192>(ws, voffw[0], base);
+        hd_dma16s<1 * 8192>(ws, voffw[1], base);
+        if (na == 3) hd_dma16s<2 * 8192>(ws, voffw[2], base);
 #endif
     };
+    static_assert(G::NA_LO == 2, "two weight groups per wave at least, a third for the first GA % 8 waves");
+    constexpr int NW_LO = G::NA_LO + G::NB, NW_HI = G::NA_HI + G::NB;     // DMA instructions per wave and K step
 
-    floatx16 acc[2][MT];
+    floatx16 acc[PT][MT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < PT; ++t)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -594,136 +627,155 @@ __global__ __launch_bounds__(hd3::NT, 2) void head_f16_kernel256h(HeadArgs a) {
     const int frag_row = lane & 31, frag_half = lane >> 5;
 
     // ---- prologue: the postnorm table by LDS-DMA FIRST (the oldest requests: every counted wait below covers them; waves 0-3 a
-    //      KiB of the scale each, waves 4-7 of the shift), then all three stages; stage 0 landed ----
+    //      KiB of the scale each, waves 4-7 of the shift) and the bias (a global load in the statistics phase costs a memory latency
+    //      per use), then every stage; stage 0 landed ----
     {
         const int idx = (wave & 3) * 512 + lane * 8;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + PRO_OFF + (wave >> 2) * 4096 + (wave & 3) * 1024);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + G::PRO_OFF + (wave >> 2) * 4096 + (wave & 3) * 1024);
         hd_dma16s<0>(wave < 4 ? a.pro_scale : a.pro_shift, (unsigned)((idx < K ? idx : 0) * 2), dst);
-        // ... and the bias (a global load in the statistics phase costs a memory latency per use)
-        hd_dma16s<0>(a.bias, (unsigned)((lane * 4 < a.C ? lane * 4 : 0) * 4), smem_base + BIAS_OFF);
+        hd_dma16s<0>(a.bias, (unsigned)((lane * 4 < a.C ? lane * 4 : 0) * 4), smem_base + G::BIAS_OFF);
     }
-    issue_step(0, 0);
-    issue_step(STAGE_BYTES, nk > 1 ? 1 : 0);
-    issue_step(2 * STAGE_BYTES, nk > 2 ? 2 : nk - 1);
+#pragma unroll
+    for (int st = 0; st < STAGES; ++st) issue_step(st * STAGE_BYTES, st < nk ? st : nk - 1);
 #if defined(METRO_DBG_HD3_NO_X) || defined(METRO_DBG_HD3_NO_W)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #else
-    if (na == 3) asm volatile("s_waitcnt vmcnt(14)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    if (na_hi) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 1) * NW_HI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 1) * NW_LO) : "memory");
 #endif
-    const float* bias_lds = reinterpret_cast<const float*>(smem + BIAS_OFF);
+    const float* bias_lds = reinterpret_cast<const float*>(smem + G::BIAS_OFF);
 
-    // fragment addresses inside a stage, per k-step of the wave's K-half (kq = 0, 1: the 16-byte chunk (2 h + kq) 2 + lane half)
-    unsigned a_addr[2][MT], b_addr[2][2];
+    // fragment addresses inside a stage, per phase of the wave's K-part (ph: the 16-byte chunk (h NP + ph) 2 + lane half)
+    unsigned a_addr[NP][MT], b_addr[NP][PT];
 #pragma unroll
-    for (int kq = 0; kq < 2; ++kq) {
-        const int chunk = (h * 2 + kq) * 2 + frag_half;
+    for (int ph = 0; ph < NP; ++ph) {
+        const int chunk = (h * NP + ph) * 2 + frag_half;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = i * 32 + frag_row;
-            a_addr[kq][i] = row * ROW_BYTES + ((chunk ^ hd_swz(row)) << 4);
+            a_addr[ph][i] = row * ROW_BYTES + ((chunk ^ hd_swz(row)) << 4);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int brow = pg * 64 + t * 32 + frag_row;
-            b_addr[kq][t] = WROWS * ROW_BYTES + brow * ROW_BYTES + ((chunk ^ hd_swz(brow)) << 4);
+        for (int t = 0; t < PT; ++t) {
+            const int brow = (pg * PT + t) * 32 + frag_row;
+            b_addr[ph][t] = WROWS * ROW_BYTES + brow * ROW_BYTES + ((chunk ^ hd_swz(brow)) << 4);
         }
     }
-    // A wave's work is a chain of PHASES (K step k, kq): ten MFMAs = five weight fragments against its two pixel fragments.  The
-    // weight fragments are read TWO MFMA pairs ahead of their use (af[parity of the phase][tile]: the last two pairs of a phase read
-    // the first two fragments of the next), the pixel fragments and table rows of the next phase during the first pairs of this one
-    // (pre-activated before the phase ends): no MFMA waits for an LDS read of its own pair.
-    half8_t af[2][MT], bq[2][2], braw[2], sc = {}, sh = {};
-    auto rd_a = [&](auto par_c, auto i_c, int soff, auto kq_c) {
+    // A wave's work is a chain of PHASES (K step k, ph): 5 PT MFMAs = five weight fragments against its PT pixel fragments.  The
+    // weight fragments are read TWO MFMA groups ahead of their use (af[parity of the phase][tile]: the last two groups of a phase
+    // read the first two fragments of the next), the pixel fragments and table rows of the next phase during this one
+    // (pre-activated before the phase ends).
+    half8_t af[2][MT], bq[2][PT], braw[PT], sc = {}, sh = {};
+    auto rd_a = [&](auto par_c, auto i_c, int soff, auto ph_c) {
         af[decltype(par_c)::value][decltype(i_c)::value] =
-            *reinterpret_cast<const half8_t*>(smem + soff + a_addr[decltype(kq_c)::value][decltype(i_c)::value]);
+            *reinterpret_cast<const half8_t*>(smem + soff + a_addr[decltype(ph_c)::value][decltype(i_c)::value]);
     };
-    auto rd_b = [&](int soff, int k0, auto kq_c) {       // both raw pixel fragments and the table rows of their 8 channels
-        constexpr int KQ = decltype(kq_c)::value;
-        braw[0] = *reinterpret_cast<const half8_t*>(smem + soff + b_addr[KQ][0]);
-        braw[1] = *reinterpret_cast<const half8_t*>(smem + soff + b_addr[KQ][1]);
-        const int chunk = (h * 2 + KQ) * 2 + frag_half;
+    auto rd_b = [&](int soff, int k0, auto ph_c) {       // the raw pixel fragments and the table rows of their 8 channels
+        constexpr int PH = decltype(ph_c)::value;
+#pragma unroll
+        for (int t = 0; t < PT; ++t) braw[t] = *reinterpret_cast<const half8_t*>(smem + soff + b_addr[PH][t]);
+        const int chunk = (h * NP + PH) * 2 + frag_half;
         sc = *reinterpret_cast<const half8_t*>(pro_lds + k0 + chunk * 8);
         sh = *reinterpret_cast<const half8_t*>(pro_lds + 2048 + k0 + chunk * 8);
     };
-    auto act = [&](auto par_c, auto t_c) {               // postnorm BN + ReLU, fp16 FMA, one rounding (resnet_v2.py:229)
+    auto act = [&](auto par_c, int t) {                  // postnorm BN + ReLU, fp16 FMA, one rounding (resnet_v2.py:229)
         const half8_t z = {};
-        bq[decltype(par_c)::value][decltype(t_c)::value] = __builtin_elementwise_max(braw[decltype(t_c)::value] * sc + sh, z);
+        bq[decltype(par_c)::value][t] = __builtin_elementwise_max(braw[t] * sc + sh, z);
     };
     auto mma = [&](auto par_c, auto i_c) {
         constexpr int P = decltype(par_c)::value, I = decltype(i_c)::value;
 #ifndef METRO_DBG_HD3_NO_MFMA
-        acc[0][I] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[P][I], bq[P][0], acc[0][I], 0, 0, 0);
-        acc[1][I] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[P][I], bq[P][1], acc[1][I], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[t][I] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[P][I], bq[P][t], acc[t][I], 0, 0, 0);
 #else
-        const half8_t a_ = af[P][I], b0_ = bq[P][0], b1_ = bq[P][1];
+        const half8_t a_ = af[P][I], b0_ = bq[P][0], b1_ = bq[P][PT - 1];
         asm volatile("" ::"v"(a_), "v"(b0_), "v"(b1_));
 #endif
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     using I4 = std::integral_constant<int, 4>;
-    // the emitted order of a segment: its LDS reads, an MFMA, half of its VALU work, the other MFMA, the rest
-#define HD3_PIN(NREAD, NVALU)                                       \
-    __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);          \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
-    __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);          \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              \
-    __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);          \
-    __builtin_amdgcn_sched_barrier(0)
+
+    // One phase: fragment set PAR, phase PH of K step k (stage at byte offset cur; the next stage at nxt).  The LAST phase of a
+    // step holds the step's barrier: every read of the stage is complete in every wave and step k + 1 has landed (this wave's
+    // share; the barrier makes it everybody's), steps k + 2 ... stay in flight and step k + STAGES goes into this stage (past the
+    // end: the last step again -- valid memory, a stage nobody reads).
+    auto phase = [&](auto par_c, auto ph_c, int cur, int nxt, int k) {
+        constexpr int P = decltype(par_c)::value, PH = decltype(ph_c)::value;
+        constexpr bool LAST = PH == NP - 1;
+        using PQ = std::integral_constant<int, P ^ 1>;
+        using NPH = std::integral_constant<int, LAST ? 0 : PH + 1>;
+        const int noff = LAST ? nxt : cur;
+        const int k1 = k + 1 < nk ? k + 1 : nk - 1;
+        const int nk0 = (LAST ? k1 : k) * BK;
+        rd_a(par_c, I2{}, cur, ph_c);
+        if constexpr (!LAST) rd_b(noff, nk0, NPH{});
+        mma(par_c, I0{});
+        hd_pin<LAST ? 1 : 3 + PT, PT, 2>();
+        rd_a(par_c, I3{}, cur, ph_c); mma(par_c, I1{}); hd_pin<1, PT, 2>();
+        rd_a(par_c, I4{}, cur, ph_c);
+        if constexpr (!LAST) act(PQ{}, 0);
+        mma(par_c, I2{});
+        hd_pin<1, PT, 4>();
+        if constexpr (LAST) {
+#if defined(METRO_DBG_HD3_NO_X) || defined(METRO_DBG_HD3_NO_W)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+            if (na_hi) hd_wait_barrier<(STAGES - 2) * NW_HI>(); else hd_wait_barrier<(STAGES - 2) * NW_LO>();
+#endif
+            issue_step(cur, k + STAGES < nk ? k + STAGES : nk - 1);
+        }
+        rd_a(PQ{}, I0{}, noff, NPH{});
+        if constexpr (LAST) rd_b(noff, nk0, NPH{});
+        if constexpr (!LAST && PT == 2) act(PQ{}, 1);
+        mma(par_c, I3{});
+        hd_pin<LAST ? 3 + PT : 1, PT, 4>();
+        rd_a(PQ{}, I1{}, noff, NPH{}); mma(par_c, I4{}); hd_pin<1, PT, 2>();
+        if constexpr (LAST) {
+#pragma unroll
+            for (int t = 0; t < PT; ++t) act(PQ{}, t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
 
     rd_b(0, 0, I0{});
     rd_a(I0{}, I0{}, 0, I0{});
     rd_a(I0{}, I1{}, 0, I0{});
-    act(I0{}, I0{});
-    act(I0{}, I1{});
+#pragma unroll
+    for (int t = 0; t < PT; ++t) act(I0{}, t);
     __builtin_amdgcn_sched_barrier(0);
 
     int cur = 0;                                   // byte offset of the stage of K step k
-    for (int k = 0; k < nk; ++k) {
-        const int nxt = cur + STAGE_BYTES == RING_BYTES ? 0 : cur + STAGE_BYTES;
-        const int k0 = k * BK;
-        const int k1 = k + 1 < nk ? k + 1 : nk - 1;
-        const int k3 = k + 3 < nk ? k + 3 : nk - 1;       // past the end: the last step again (valid memory, a stage nobody reads)
-        // ---- phase (k, 0) ----
-        rd_a(I0{}, I2{}, cur, I0{}); rd_b(cur, k0, I1{}); mma(I0{}, I0{}); HD3_PIN(5, 2);
-        rd_a(I0{}, I3{}, cur, I0{}); mma(I0{}, I1{}); HD3_PIN(1, 2);
-        rd_a(I0{}, I4{}, cur, I0{}); act(I1{}, I0{}); mma(I0{}, I2{}); HD3_PIN(1, 4);
-        rd_a(I1{}, I0{}, cur, I1{}); act(I1{}, I1{}); mma(I0{}, I3{}); HD3_PIN(1, 4);
-        rd_a(I1{}, I1{}, cur, I1{}); mma(I0{}, I4{}); HD3_PIN(1, 2);
-        // ---- phase (k, 1) ----
-        rd_a(I1{}, I2{}, cur, I1{}); mma(I1{}, I0{}); HD3_PIN(1, 2);
-        rd_a(I1{}, I3{}, cur, I1{}); mma(I1{}, I1{}); HD3_PIN(1, 2);
-        rd_a(I1{}, I4{}, cur, I1{}); mma(I1{}, I2{}); HD3_PIN(1, 2);
-        // every read of this stage is complete in every wave and step k + 1 has landed (this wave's share; the barrier makes it
-        // everybody's); step k + 2 stays in flight, step k + 3 goes into this stage
-#if defined(METRO_DBG_HD3_NO_X) || defined(METRO_DBG_HD3_NO_W)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-        if (na == 3) hd_wait_barrier<7>(); else hd_wait_barrier<6>();
-#endif
-        issue_step(cur, k3);
-        rd_a(I0{}, I0{}, nxt, I0{}); rd_b(nxt, k1 * BK, I0{}); mma(I1{}, I3{}); HD3_PIN(5, 2);
-        rd_a(I0{}, I1{}, nxt, I0{}); mma(I1{}, I4{}); HD3_PIN(1, 2);
-        act(I0{}, I0{});
-        act(I0{}, I1{});
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
+    auto next_of = [&](int off) { return off + STAGE_BYTES == RING_BYTES ? 0 : off + STAGE_BYTES; };
+    if constexpr (NP == 2) {
+        for (int k = 0; k < nk; ++k) {
+            const int nxt = next_of(cur);
+            phase(I0{}, I0{}, cur, nxt, k);
+            phase(I1{}, I1{}, cur, nxt, k);
+            cur = nxt;
+        }
+    } else {
+        for (int k = 0; k < nk; k += 2) {          // one phase per step: the fragment sets alternate by step (nk is even)
+            const int nxt = next_of(cur), nxt2 = next_of(nxt);
+            phase(I0{}, I0{}, cur, nxt, k);
+            phase(I1{}, I0{}, nxt, nxt2, k + 1);
+            cur = nxt2;
+        }
     }
-#undef HD3_PIN
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the re-requested tail has landed everywhere: the
                                                                                  // logits tiles overlay the ring
 
-    // ---- K-halves -> fp32 logits (+ bias) of the pair's 32 pixels, then the per-joint statistics, twice (32 pixels each) ----
-    float* lt = reinterpret_cast<float*>(smem) + pg * (32 * LROW);
+    // ---- K-parts -> fp32 logits (+ bias) of the group's 32 pixels, then the per-joint statistics, 32 pixels at a time ----
+    float* lt0 = reinterpret_cast<float*>(smem) + pg * (KSPLIT - 1) * (32 * LROW);     // the group's tiles: part h writes tile h - 1
     const float step_s = 1.0f / (float)(a.side - 1);
     const float step_d = 1.0f / (float)(a.D - 1);
 #ifdef METRO_DBG_HD3_NO_SOFTMAX
-    if (a.J > 0) { float v = 0.f; for (int t = 0; t < 2; ++t) for (int i = 0; i < MT; ++i) v += acc[t][i][t + i]; if (v == 12345.f) a.partials[tid] = v; return; }
+    if (a.J > 0) { float v = 0.f; for (int t = 0; t < PT; ++t) for (int i = 0; i < MT; ++i) v += acc[t][i][t + i]; if (v == 12345.f) a.partials[tid] = v; return; }
 #endif
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (h == 1) {
+    for (int t = 0; t < PT; ++t) {
+        if (h > 0) {
+            float* lt = lt0 + (h - 1) * (32 * LROW);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -742,33 +794,37 @@ __global__ __launch_bounds__(hd3::NT, 2) void head_f16_kernel256h(HeadArgs a) {
                     const int c0 = i * 32 + 8 * q + 4 * frag_half;
                     const floatx4 bv = *reinterpret_cast<const floatx4*>(bias_lds + c0);     // words past the head's channels: unused
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)      // (first K-half + second K-half) + bias: a fixed order
-                        lt[frag_row * LROW + c0 + e] = (acc[t][i][4 * q + e] + lt[frag_row * LROW + c0 + e]) + bv[e];
+                    for (int e = 0; e < 4; ++e) {      // ((part 0 + part 1) + ...) + bias: a fixed order
+                        float v = acc[t][i][4 * q + e];
+#pragma unroll
+                        for (int r = 0; r < KSPLIT - 1; ++r) v += lt0[r * (32 * LROW) + frag_row * LROW + c0 + e];
+                        lt0[frag_row * LROW + c0 + e] = v + bv[e];
+                    }
                 }
         }
         __syncthreads();
-        const int p0 = pg * 64 + t * 32;                          // first pixel of the tile inside the block
+        const int p0 = (pg * PT + t) * 32;                        // first pixel of the tile inside the block
         if (a.logits_out != nullptr) {
-            for (int idx = h * 64 + lane; idx < 32 * a.C; idx += 128) {
+            for (int idx = h * 64 + lane; idx < 32 * a.C; idx += KSPLIT * 64) {
                 const int p = idx / a.C, c = idx - p * a.C;
-                a.logits_out[(size_t)(m0 + p0 + p) * a.C + c] = lt[p * LROW + c];
+                a.logits_out[(size_t)(m0 + p0 + p) * a.C + c] = lt0[p * LROW + c];
             }
         }
         const int pim = tile * TN + p0 + frag_row;                // pixel index inside the image
         const int py = pim / a.side, px = pim - py * a.side;
         const float cx = (float)px * step_s, cy = (float)py * step_s;
-        const int slab = tile * (TN / 32) + pg * 2 + t;
+        const int slab = tile * (TN / 32) + pg * PT + t;
         float* rec = a.partials + ((size_t)img * a.slabs + slab) * a.J * 5;
-        hd_tile_stats(lt + frag_row * LROW, a.J, a.D, h * 2 + frag_half, 4, cx, cy, step_d, frag_row == 0,
+        hd_tile_stats(lt0 + frag_row * LROW, a.J, a.D, h * 2 + frag_half, 2 * KSPLIT, cx, cy, step_d, frag_row == 0,
                       [&](int j, float m, float s_, float sx, float sy, float sz) {
                           float* o5 = rec + j * 5;
                           o5[0] = m; o5[1] = s_; o5[2] = sx; o5[3] = sy; o5[4] = sz;
                       });
-        __syncthreads();                                          // the tile is rewritten in the next round
+        if (t + 1 < PT) __syncthreads();                          // the tiles are rewritten in the next round
     }
 }
 
-// heads this launch is built for: fp16 input, whole 128-pixel slabs per image, at most 160 channels, K in whole steps
+// heads this launch is built for: fp16 input, whole 64-pixel slabs per image, at most 160 channels, K in whole steps
 bool head_f16_supported(int c_in, int c_head, int n_joints, int depth, int side) {
     static const int enabled = tuning_knob("METRO_HEAD_FUSED", 1);
     const int pixels = side * side;
@@ -780,10 +836,34 @@ static bool head_f16_big(int n, int side) {
     static const int t256 = tuning_knob("METRO_HEAD_256", 1);
     return t256 && (side * side) % hd2::TN == 0 && (long)n * (side * side / hd2::TN) >= 256;
 }
-// records per image: one per 64 pixels (64-pixel tiles) or per 32 (256-pixel tiles); the partials slot is sized for the larger
+// Which kernel runs a head at batch n: 0 = 64-pixel tiles (round 2), 1 = 256-pixel tiles over the whole K (round 3), 2 / 3 / 4 = the
+// ring kernel with 256- / 128- / 64-pixel tiles (round 4).  The ring kernel's phases alternate two fragment sets by step when a wave
+// has one phase per step: an even number of 64-channel K steps, at least as many as it has stages.
+static int head_f16_variant(int n, int c_in, int c_head, int side) {
+    static const int ring = tuning_knob("METRO_HEAD_RING", 1);
+    const int pixels = side * side;
+    const bool ring_ok = ring && c_in % 128 == 0 && c_in / 64 >= 6;
+    if (head_f16_big(n, side)) return ring_ok && c_head <= 144 ? 2 : 1;
+    if (!ring_ok) return 0;
+    if (pixels % 128 == 0 && (long)n * (pixels / 128) >= 256) return 3;
+    return 4;
+}
+// records per image: one per 32 pixels (every kernel but the 64-pixel one of round 2); the partials slot is sized for the larger
 int head_f16_slabs(int side) { return side * side / 32; }
 // ... and what a launch at batch n writes (= what softargmax_finalize must fold)
-int head_f16_records(int n, int side) { return head_f16_big(n, side) ? side * side / 32 : side * side / hd::TN; }
+int head_f16_records(int n, int c_in, int c_head, int side) {
+    return head_f16_variant(n, c_in, c_head, side) == 0 ? side * side / hd::TN : side * side / 32;
+}
+
+template <int TN, int KSPLIT, int WROWS>
+static int launch_head_ring(const HeadArgs& a, int n, int side, hipStream_t stream) {
+    using G = HeadRing<TN, KSPLIT, WROWS>;
+    auto kern = head_f16_ring_kernel<TN, KSPLIT, WROWS>;
+    static PerDeviceInt done;
+    if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), G::LDS_BYTES, done, "head_f16<ring>")) return st;
+    hipLaunchKernelGGL(kern, dim3(side * side / TN, n), dim3(G::NT), G::LDS_BYTES, stream, a);
+    return launch_status("head_f16<ring>");
+}
 
 int launch_head_f16(const void* x, const void* w, const float* bias, const void* pro_scale, const void* pro_shift,
                     int n, int c_in, int c_head, int n_joints, int depth, int side, float* partials, float* logits_out,
@@ -792,23 +872,21 @@ int launch_head_f16(const void* x, const void* w, const float* bias, const void*
         set_error("head_f16: unsupported head (c_in %d, %d channels = %d joints x depth %d, side %d)", c_in, c_head, n_joints, depth, side);
         return METRO_ERR_UNSUPPORTED;
     }
-    const bool big = head_f16_big(n, side);
-    static const int halves = tuning_knob("METRO_HEAD_256H", 1);
-    const bool bigh = big && halves && c_head <= hd3::WROWS && c_in / hd3::BK >= hd3::STAGES;
-    if (note_kernel(bigh ? "head_f16<144x256,khalves>" : big ? "head_f16<160x256>" : "head_f16<160x64>")) return METRO_OK;
+    const int variant = head_f16_variant(n, c_in, c_head, side);
+    const int wrows = c_head <= 144 ? 144 : 160;
+    if (variant >= 2 ? note_kernel("head_f16<%dx%d,k%d>", wrows, variant == 2 ? 256 : variant == 3 ? 128 : 64, variant == 2 ? 2 : 4)
+                     : note_kernel(variant == 1 ? "head_f16<160x256>" : "head_f16<160x64>"))
+        return METRO_OK;
     HeadArgs a;
     a.x = static_cast<const half_t*>(x); a.w = static_cast<const half_t*>(w); a.bias = bias;
     a.pro_scale = static_cast<const half_t*>(pro_scale); a.pro_shift = static_cast<const half_t*>(pro_shift);
     a.partials = partials; a.logits_out = logits_out;
     a.K = c_in; a.C = c_head; a.J = n_joints; a.D = depth; a.side = side; a.pixels = side * side;
-    a.slabs = head_f16_records(n, side);
-    if (bigh) {
-        static PerDeviceInt done3;
-        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(head_f16_kernel256h), hd3::LDS_BYTES, done3, "head_f16<256h>")) return st;
-        hipLaunchKernelGGL(head_f16_kernel256h, dim3(side * side / hd3::TN, n), dim3(hd3::NT), hd3::LDS_BYTES, stream, a);
-        return launch_status("head_f16<256h>");
-    }
-    if (big) {
+    a.slabs = head_f16_records(n, c_in, c_head, side);
+    if (variant == 2) return launch_head_ring<256, 2, 144>(a, n, side, stream);
+    if (variant == 3) return wrows == 144 ? launch_head_ring<128, 4, 144>(a, n, side, stream) : launch_head_ring<128, 4, 160>(a, n, side, stream);
+    if (variant == 4) return wrows == 144 ? launch_head_ring<64, 4, 144>(a, n, side, stream) : launch_head_ring<64, 4, 160>(a, n, side, stream);
+    if (variant == 1) {
         static PerDeviceInt done2;
         if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(head_f16_kernel256), hd2::LDS_BYTES, done2, "head_f16<256>")) return st;
         hipLaunchKernelGGL(head_f16_kernel256, dim3(side * side / hd2::TN, n), dim3(hd2::NT), hd2::LDS_BYTES, stream, a);

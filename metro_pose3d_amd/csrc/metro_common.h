@@ -291,7 +291,7 @@ int launch_softargmax_finalize(const float* partials, const SoftArgmaxArgs& a, i
 // the volumetric head in one launch (head_f16.hip): postnorm prologue + logits GEMM + per-joint softmax statistics
 bool head_f16_supported(int c_in, int c_head, int n_joints, int depth, int side);
 int head_f16_slabs(int side);               // records per image the partials slot must hold
-int head_f16_records(int n, int side);      // records per image a launch at batch n writes
+int head_f16_records(int n, int c_in, int c_head, int side);      // records per image a launch at batch n writes
 int launch_head_f16(const void* x, const void* w, const float* bias, const void* pro_scale, const void* pro_shift,
                     int n, int c_in, int c_head, int n_joints, int depth, int side, float* partials, float* logits_out,
                     hipStream_t stream);

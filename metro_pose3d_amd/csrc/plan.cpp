@@ -99,6 +99,7 @@ struct Layer {
     int p1_w, p1_bias, p1_scale, p1_shift;
     int psc_w, psc_bias, psc_scale, psc_shift, psc_slot;
     int stem_pool;        // stem conv + max-pool in one launch (the layer's output is the pooled tensor)
+    int head_c_in;        // soft-argmax layer of a fused head: input channels of the logits GEMM (which head kernel ran)
     int head_fused;       // logits layer: GEMM + per-joint softmax statistics in one launch (head_f16.hip); the
                           // soft-argmax layer behind it then only finalizes
 };
@@ -558,6 +559,7 @@ int build_plan(MetroPlan* p) {
         L.in_slot = S_LOGITS; L.out_slot = S_NONE; L.res_slot = S_NONE;
         L.p_w = L.p_bias = L.p_scale = L.p_shift = -1;
         L.head_fused = head_fused ? 1 : 0;
+        L.head_c_in = cur_c;
         B.fill_info(L, "softargmax", 0.0);
         p->layers.push_back(L);
     }
@@ -691,7 +693,8 @@ int launch_layer(const MetroPlan* p, const char* d_params, int li, const float* 
             if (poses == nullptr) { set_error("metro_forward: poses_out is NULL"); return METRO_ERR_INVALID_ARG; }
             const SoftArgmaxArgs a = make_softargmax_args(p->spec, n);
             if (L.head_fused)
-                return launch_softargmax_finalize(static_cast<const float*>(slot_ptr(S_PART)), a, head_f16_records(n, a.side), poses, stream, nullptr,
+                return launch_softargmax_finalize(static_cast<const float*>(slot_ptr(S_PART)), a,
+                                                  head_f16_records(n, L.head_c_in, a.depth * a.n_joints_head, a.side), poses, stream, nullptr,
                                                   static_cast<int32_t*>(slot_ptr(S_STATUS)));
             // precise: 0 fp32 / fp32, 1 fp32 logits + fp64 accumulators (F32 and F32M modes), 2 fp64 / fp64
             return launch_softargmax(slot_ptr(L.in_slot), a, p->spec.precision == METRO_PREC_F32M ? 1 : p->spec.precision, slot_ptr(S_PART), poses, stream,
@@ -1145,7 +1148,8 @@ int metro_head_f16(const void* d_x, const void* d_w, const float* d_bias, const 
                              spec->n_joints_head, spec->depth, side, static_cast<float*>(d_partials), d_logits_out,
                              static_cast<hipStream_t>(stream));
     if (st) return st;
-    return launch_softargmax_finalize(static_cast<const float*>(d_partials), a, head_f16_records(n, side), d_poses_out,
+    return launch_softargmax_finalize(static_cast<const float*>(d_partials), a,
+                                      head_f16_records(n, c_in, spec->depth * spec->n_joints_head, side), d_poses_out,
                                       static_cast<hipStream_t>(stream));
 }
 

@@ -372,6 +372,8 @@ int launch_stem_pool_f32in(const float* images, const void* w, const float* bias
     a.n = n; a.side = side;
     const int ppr = side / 4 / sp::PP;
     a.n_patches = n * ppr * ppr;
+    static const int split = sp_env_int("METRO_STEM_RAW_SPLIT", 2);
+    if (split == 1) return launch_sp<1, true>(a, stream);
     return launch_sp<2, true>(a, stream);
 }
 

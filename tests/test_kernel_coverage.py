@@ -74,8 +74,11 @@ def test_every_layer_names_its_kernel_without_a_gpu():
     small = {li.name.decode(): kid for _, li, kid in dispatch_table(ModelSpec(101, 8, 'many19'), 1)}
     assert small['block3/unit_2/conv2'] != ids['C4-rn101-s8-J19-b32']['block3/unit_2/conv2']
     # the one-launch head and its finalize
-    assert ids['C2-rn50-s16-J17-b64']['logits'] == 'head_f16<160x64>'
-    assert ids['C2-rn50-s16-J17-b256']['logits'] == ids['C5-rn50-s4-J17-b16']['logits'] == 'head_f16<144x256,khalves>'
+    # (head_f16.hip: tile width by the number of tiles, weight rows by the head's channels, K-parts per wave group)
+    assert ids['C1-rn50-s32-J17-b1']['logits'] == ids['C2-rn50-s16-J17-b64']['logits'] == 'head_f16<144x64,k4>'
+    assert ids['C3-rn50-s16-J19-b64']['logits'] == 'head_f16<160x64,k4>'
+    assert ids['C4-rn101-s8-J19-b32']['logits'] == 'head_f16<160x128,k4>'
+    assert ids['C2-rn50-s16-J17-b256']['logits'] == ids['C5-rn50-s4-J17-b16']['logits'] == 'head_f16<144x256,k2>'
     assert ids['C3-rn50-s16-J19-b256']['logits'] == 'head_f16<160x256>'
     assert ids['C2-rn50-s16-J17-b64']['softargmax'] == 'softargmax_finalize<acc32>'
     # parity modes name their kernels too
@@ -98,11 +101,11 @@ def test_head_partials_slot_covers_large_heat_maps(lib, nb):
     infos = eng.layer_infos()
     logits = next(li for li in infos if li.name == b'logits')
     kern = eng.layer_kernels(nb)[infos.index(logits)]
-    assert kern == 'head_f16<144x256,khalves>' if nb == 8 else kern.startswith('head_f16<') and 'x256' not in kern, kern
+    assert kern == 'head_f16<144x256,k2>' if nb == 8 else kern.startswith('head_f16<') and 'x256' not in kern, kern
     side, j = 96, spec.skeleton.n_head
     after_logits = logits.out_offset + logits.out_bytes_per_image * nb
     need = lib.metro_head_f16_scratch_bytes(nb, side, j)
-    assert need >= nb * (side * side // (32 if nb == 8 else 64)) * j * 5 * 4          # the worst case at this batch: a record per 32 pixels
+    assert need >= nb * (side * side // 32) * j * 5 * 4          # a record per 32 pixels
     status = -(-nb * 4 // 256) * 256
     assert eng.workspace_bytes - after_logits - status >= need, (eng.workspace_bytes - after_logits - status, need)
 

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 V="HD3_NO_X HD3_NO_W HD3_NO_X+HD3_NO_W HD3_NO_MFMA HD3_NO_SOFTMAX HD3_NO_X+HD3_NO_W+HD3_NO_SOFTMAX"
 ls metro_pose3d_amd/dbg/libmetro_HD3_NO_X.so >/dev/null 2>&1 || tools/build_dbg_variants.sh head_f16.hip $V >/dev/null
-echo "== product"; python tools/head_probe.py 2>&1 | grep "b256\|C5"
+echo "== product"; python tools/head_probe.py 2>&1 | grep "b64\|b256\|C4\|C5"
 for v in $V; do
-  echo "== $v"; METRO_HIP_LIB=$PWD/metro_pose3d_amd/dbg/libmetro_$v.so python tools/head_probe.py 2>&1 | grep "b256\|C5"
+  echo "== $v"; METRO_HIP_LIB=$PWD/metro_pose3d_amd/dbg/libmetro_$v.so python tools/head_probe.py 2>&1 | grep "b64\|b256\|C4\|C5"
 done

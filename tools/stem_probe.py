@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 from metro_pose3d_amd import _lib
 from tests import helpers as H
 lib = _lib.load(); dev = torch.device('cuda', 0)
-n = 64
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 x = torch.rand((n, 256, 256, 3), dtype=torch.float32, device=dev)
 w = (torch.randn((64, 7, 8, 4), device=dev) * 0.05).half()
 b = torch.zeros(64, dtype=torch.float32, device=dev)
