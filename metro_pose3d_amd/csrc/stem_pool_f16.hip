@@ -328,6 +328,286 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the stem for 256 x 256 crops with the max-pool IN REGISTERS (stem_pool_rows_kernel).
+// The kernel above spends 19 us moving crops in and pooled rows out, 31 us in its conv phase (7 of them MFMAs, 10 the conv -> LDS
+// writes) and 9 us pooling out of LDS: 400 KB of LDS traffic per 8 x 8 pooled patch, three barrier-separated phases per patch.  Here
+// the conv pixels are the ROWS of the MFMA (A = pixel fragments from the LDS window, B = the launch-resident weight fragments), so a
+// lane holds 16 conv pixels of ONE channel: with row m of a 32-pixel tile = conv column 32 w + m, lane half h' holds the column
+// quads 8 q + 4 h' + {0..3} = (E[2g], O[2g], E[2g+1], O[2g+1]), g = 2 q + h' (E / O: even / odd conv columns) and
+//     pooled X = 2g + 1 = max(O[2g], E[2g+1], O[2g+1])                           in the lane,
+//     pooled X = 2g     = max(O[2g-1], E[2g], O[2g]),  O[2g-1] from the other lane half (one 32-lane exchange of a packed pair per quad);
+// the vertical 3-max runs over consecutive conv rows of the same lane (a rolling carry), zero rows / columns of the pool's padding
+// (resnet_utils.py:138-185) are the initial carry / exchange value.  Only column 16 w of x-tile w needs a value of ANOTHER wave
+// (O of the left neighbour's last column): each wave also pools that column of its own (the "edge") and the store phase folds it in.
+//   * block = 4 waves = the 4 x-tiles of a band of 8 pooled rows x the full width (no horizontal halo; one conv row of vertical halo:
+//     6 % recompute against 13 % + 10 % tile padding above: 32.0 GFLOP issued at batch 64 instead of 37.6); every wave all 64
+//     channels (112 VGPRs of weights; a pixel fragment is read once for both channel tiles);
+//   * the band is walked one conv row per barrier: the fp32 crop rows come by LDS-DMA into a staging ring three rows of conv ahead,
+//     are cast into the zero-bordered 4-channel fp16 window ring (architectures.py:29) one row of conv ahead;
+//   * pooled rows leave through an 8 KiB LDS tile ([X][channel], for 16-byte stores): 24 KB of LDS writes + reads per pooled row
+//     against 111 KB of conv tile traffic before.
+// Bit-identical to the kernel above (same k order per output, same fp16 rounding before the max).
+namespace sp2 {
+constexpr int SIDE = 256, PS = 64, PY = 8, NW = 4, NT = 256, KK = 14;      // crop side, pooled side, pooled rows per band
+constexpr int WROW = (SIDE + 8) * 8;          // bordered fp16 4-channel row: 2112 bytes
+constexpr int NWR = 16;                       // window ring rows (a conv row uses 7, the next one's 2 new rows are cast meanwhile)
+constexpr int SROW = SIDE * 12;               // fp32 crop row: 3072 bytes = 3 LDS-DMA instructions
+constexpr int NSR = 8;                        // staging ring rows: 3 conv rows of lead (6 crop rows in flight) + 2 being cast
+constexpr int LEAD = 3;
+constexpr int OUT_BYTES = PS * 128;           // pooled row tile [64 X][64 channels] fp16
+constexpr int EDGE_BYTES = NW * 128;          // per pooled row: the edge column of every x-tile [64 channels] fp16
+constexpr int WIN_OFF = 0;
+constexpr int STG_OFF = WIN_OFF + NWR * WROW;
+constexpr int OUT_OFF = STG_OFF + NSR * SROW;
+constexpr int EDGE_OFF = OUT_OFF + 2 * OUT_BYTES;
+constexpr int LDS_BYTES = EDGE_OFF + 2 * EDGE_BYTES;      // 75 776: two blocks per CU
+}  // namespace sp2
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+// packed fp16 max as the instruction (the builtin canonicalises both operands first: a third of the pooling's VALU work)
+__device__ __forceinline__ half2_t sp2_max(half2_t a, half2_t b) {
+    half2_t r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ half2_t sp2_max_pair_hi(half2_t p) {      // (max(lo, hi), hi)
+    half2_t r;
+    asm("v_pk_max_f16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(p));
+    return r;
+}
+__device__ __forceinline__ half2_t sp2_max_pair_both(half2_t p) {    // (max(lo, hi), max(lo, hi))
+    half2_t r;
+    asm("v_pk_max_f16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1]" : "=v"(r) : "v"(p));
+    return r;
+}
+__device__ __forceinline__ half2_t sp2_hi_lo(half2_t a, half2_t b) {        // (a.hi, b.lo)
+    return __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x05040302u));
+}
+__device__ __forceinline__ half2_t sp2_xchg32(half2_t v) {          // the value of lane ^ 32
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(half2_t, __shfl_xor(i, 32, 64));
+}
+
+__global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs a) {
+    using namespace sp2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    const unsigned smem_base = (unsigned)(size_t)(lds_void_t*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // x-tile: conv columns 32 w ..., pooled columns 16 w ...
+    const int n = lane & 31, hh = lane >> 5;
+    const int img = blockIdx.x / (PS / PY), band = blockIdx.x % (PS / PY);
+    const int Y0 = band * PY;
+    const int ylo = Y0 == 0 ? 0 : 2 * Y0 - 1, yhi = 2 * Y0 + 2 * PY - 1;      // conv rows of the band (row -1 is the pool's zero row)
+
+    // ---- launch-resident weights as B fragments: both 32-channel tiles, 14 k-steps; the per-lane bias of its two channels ----
+    half8_t wf[2][KK];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(i * 32 + n) * 224 + kk * 16 + hh * 8);
+    float bias_l[2] = {a.bias[n], a.bias[32 + n]};
+    // every ordinary load is waited for HERE: a compiler-placed wait at the first use inside the row loop would be a vmcnt(0) per row
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) asm volatile("" : "+v"(wf[i][kk]));
+    asm volatile("" : "+v"(bias_l[0]), "+v"(bias_l[1]));
+
+    const float* crop = a.img_f32 + (size_t)img * SIDE * SIDE * 3;
+    // crop row i (clamped: rows outside the crop are cast to zeros whatever arrived) -> staging slot i & 7: waves 0-2 a KiB each
+    auto issue_row = [&](int i) {
+#ifdef METRO_DBG_SP2_NO_DMA
+        if (a.n < 0)
+#endif
+        if (wave < 3) {
+            const int ic = i < 0 ? 0 : i > SIDE - 1 ? SIDE - 1 : i;
+            const float* src = crop + (size_t)ic * SIDE * 3 + wave * 256 + lane * 4;
+            sp_dma16(src, __builtin_amdgcn_readfirstlane(smem_base + STG_OFF + (i & (NSR - 1)) * SROW + wave * 1024));
+        }
+    };
+    // window row p (bordered: crop row p - 3) from its staging slot: thread = pixel
+    auto cast_row = [&](int p) {
+        const int i = p - 3;
+        const float* s3 = reinterpret_cast<const float*>(smem + STG_OFF + (i & (NSR - 1)) * SROW) + tid * 3;
+        const bool ok = (unsigned)i < (unsigned)SIDE;
+        const float r = s3[0], g = s3[1], b = s3[2];
+        half4_t v = {(half_t)(ok ? r : 0.f), (half_t)(ok ? g : 0.f), (half_t)(ok ? b : 0.f), (half_t)0};
+        *reinterpret_cast<half4_t*>(smem + WIN_OFF + (p & (NWR - 1)) * WROW + (tid + 3) * 8) = v;
+    };
+
+    // pooling state per channel tile: packed pairs (X = 2g, 2g + 1) per quad q; the edge column (its last O) likewise
+    half2_t carry[2][4], mid[2][4], ecarry[2], emid[2];
+    const half2_t zero2 = {(half_t)0, (half_t)0};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { carry[i][q] = zero2; mid[i][q] = zero2; }
+        ecarry[i] = zero2; emid[i] = zero2;
+    }
+    const unsigned lane_win = (unsigned)(512 * wave + 16 * n + 16 * hh);      // byte of the lane's pixel pair inside a window row
+
+    // ---- pipeline fill: the seven window rows of the band's first conv row, then the requests of the first three iterations ----
+    {
+        const int i0 = 2 * ylo - 3;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) issue_row(i0 + r);
+        // zero window meanwhile (the borders stay zero: the cast only writes the 256 interior pixels of a row)
+        for (int i = tid; i < NWR * WROW / 16; i += NT) reinterpret_cast<uint4*>(smem + WIN_OFF)[i] = make_uint4(0, 0, 0, 0);
+        sp_wait_vm<0>();
+        sp_barrier();
+#pragma unroll
+        for (int r = 0; r < 7; ++r) cast_row(2 * ylo + r);
+        sp_barrier();            // the staging slots are free again
+#pragma unroll
+        for (int j = 0; j < LEAD; ++j) {
+            issue_row(2 * (ylo + j) + 7 - 3);
+            issue_row(2 * (ylo + j) + 8 - 3);
+        }
+    }
+    // One iteration per conv row y: request of the crop rows that iteration y + 3 casts, conv + pooling of row y, cast of the window
+    // rows 2y + 7, 2y + 8 (conv row y + 1's new rows).
+    for (int y = ylo; y <= yhi; ++y) {
+        // the crop rows cast in this iteration were requested three iterations ago: two iterations of requests (2 each) are
+        // younger.  The pooled-row stores in between are not counted: requests land in order among themselves, so "at most 4
+        // operations outstanding" implies these two have landed whatever the stores do
+        if (wave < 3) sp_wait_vm<4>();
+        sp_barrier();            // ... and everybody's share has landed; conv row y - 1 is done with window rows 2y - 2, 2y - 1
+        // ---- store phase: the pooled row finished in the last iteration ----
+        {
+            const int yp = y - 1;
+            if (yp >= ylo && (yp & 1) && yp != 2 * Y0 - 1) {
+                const int Y = (yp - 1) >> 1;
+                const char* ot = smem + OUT_OFF + (Y & 1) * OUT_BYTES;
+                const char* et = smem + EDGE_OFF + (Y & 1) * EDGE_BYTES;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int c = tid + r * NT;
+                    const int X = c >> 3, c8 = c & 7;
+                    half8_t v = *reinterpret_cast<const half8_t*>(ot + X * 128 + c8 * 16);
+                    if ((X & 15) == 0 && X > 0)       // O of the left x-tile's last column, pooled over the same three rows
+                        v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t*>(et + ((X >> 4) - 1) * 128 + c8 * 16));
+                    store_out16<1>(a.out + (((size_t)img * PS + Y) * PS + X) * 64 + c8 * 8, *reinterpret_cast<const uint4*>(&v));
+                }
+            }
+        }
+        issue_row(2 * (y + LEAD) + 7 - 3);
+        issue_row(2 * (y + LEAD) + 8 - 3);
+
+        {
+            // ---- conv row y: 14 k-steps, pixel fragments straight from the window (tap row kk >> 1, pixels 4 (kk & 1) + 2 h' ...) ----
+            floatx16 acc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int slot = (2 * y + (kk >> 1)) & (NWR - 1);
+                const half8_t pf = *reinterpret_cast<const half8_t*>(smem + WIN_OFF + slot * WROW + lane_win + (kk & 1) * 32);
+#ifdef METRO_DBG_SP2_NO_MFMA      // timing experiments only (tools/build_dbg_variants.sh)
+                acc[0][kk] += (float)pf[0] * (float)wf[0][kk][0];
+                acc[1][kk] += (float)pf[1] * (float)wf[1][kk][1];
+#else
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, wf[0][kk], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, wf[1][kk], acc[1], 0, 0, 0);
+#endif
+            }
+#ifdef METRO_DBG_SP2_NO_POOL
+            if (acc[0][0] + acc[1][1] + acc[0][5] + acc[1][9] == 12345.f) a.out[tid] = (half_t)1;
+            if (a.n < 0)
+#endif
+            {
+            // ---- bias, fp16 (the value the reference's conv stores), horizontal 3-max, rolling vertical 3-max ----
+            const bool halo = y == 2 * Y0 - 1;              // the row above the band: only feeds the carry
+            const bool odd = y & 1;
+            half2_t P0[2][4], P1[2][4], R[2][4];             // (E[2g], O[2g]), (E[2g+1], O[2g+1]) per quad; the other half's P1
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    P0[i][q][0] = (half_t)(acc[i][4 * q + 0] + bias_l[i]);
+                    P0[i][q][1] = (half_t)(acc[i][4 * q + 1] + bias_l[i]);
+                    P1[i][q][0] = (half_t)(acc[i][4 * q + 2] + bias_l[i]);
+                    P1[i][q][1] = (half_t)(acc[i][4 * q + 3] + bias_l[i]);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) R[i][q] = sp2_xchg32(P1[i][q]);
+            // quad -1 is the left x-tile's (its O is folded in by the store phase: -inf here) or, for x-tile 0, the pool's zero column
+            half2_t left;
+            left[0] = (half_t)0;
+            left[1] = wave == 0 ? (half_t)0 : (half_t)-INFINITY;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                half2_t hp[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // O[2g - 1] (the high half of): lane half 1 <- half 0's quad q; half 0 <- half 1's quad q - 1
+                    const half2_t tsrc = hh ? R[i][q] : (q == 0 ? left : R[i][q > 0 ? q - 1 : 0]);
+                    const half2_t A = sp2_max_pair_hi(P0[i][q]);         // (max(E0, O0), O0)
+                    const half2_t C = sp2_max_pair_both(P1[i][q]);       // (max(E1, O1), same)
+                    hp[q] = sp2_max(A, sp2_hi_lo(tsrc, C));              // (max(T, E0, O0), max(O0, E1, O1))
+                }
+                half2_t eh = R[i][3];                         // its high half: the tile's last O (lane half 0 holds half 1's quad 3)
+                if (halo) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) carry[i][q] = hp[q];
+                    ecarry[i] = eh;
+                } else if (!odd) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mid[i][q] = hp[q];
+                    emid[i] = eh;
+                } else {
+                    const int Y = (y - 1) >> 1;
+                    char* ot = smem + OUT_OFF + (Y & 1) * OUT_BYTES;
+                    char* et = smem + EDGE_OFF + (Y & 1) * EDGE_BYTES;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const half2_t pooled = sp2_max(sp2_max(carry[i][q], mid[i][q]), hp[q]);
+                        const int X = 16 * wave + 2 * (2 * q + hh);
+                        *reinterpret_cast<half_t*>(ot + X * 128 + (i * 32 + n) * 2) = pooled[0];
+                        *reinterpret_cast<half_t*>(ot + (X + 1) * 128 + (i * 32 + n) * 2) = pooled[1];
+                        carry[i][q] = hp[q];
+                    }
+                    const half2_t ep = sp2_max(sp2_max(ecarry[i], emid[i]), eh);
+                    if (hh == 0) *reinterpret_cast<half_t*>(et + wave * 128 + (i * 32 + n) * 2) = ep[1];
+                    ecarry[i] = eh;
+                }
+            }
+            }
+        }
+        // ---- cast the window rows of conv row y + 1 (their crop rows landed before this iteration's barrier) ----
+#ifdef METRO_DBG_SP2_NO_CAST
+        if (a.n < 0)
+#endif
+        {
+            cast_row(2 * y + 7);
+            cast_row(2 * y + 8);
+        }
+    }
+    sp_barrier();
+    {   // the band's last pooled row
+        const int Y = (yhi - 1) >> 1;
+        const char* ot = smem + OUT_OFF + (Y & 1) * OUT_BYTES;
+        const char* et = smem + EDGE_OFF + (Y & 1) * EDGE_BYTES;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int c = tid + r * NT;
+            const int X = c >> 3, c8 = c & 7;
+            half8_t v = *reinterpret_cast<const half8_t*>(ot + X * 128 + c8 * 16);
+            if ((X & 15) == 0 && X > 0)
+                v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t*>(et + ((X >> 4) - 1) * 128 + c8 * 16));
+            store_out16<1>(a.out + (((size_t)img * PS + Y) * PS + X) * 64 + c8 * 8, *reinterpret_cast<const uint4*>(&v));
+        }
+    }
+}
+
 static int sp_env_int(const char* name, int dflt) { return tuning_knob(name, dflt); }
 
 bool stem_pool_f16_supported(int side, int base_width) {
@@ -372,6 +652,14 @@ int launch_stem_pool_f32in(const float* images, const void* w, const float* bias
     a.n = n; a.side = side;
     const int ppr = side / 4 / sp::PP;
     a.n_patches = n * ppr * ppr;
+    static const int rows = sp_env_int("METRO_STEM_ROWS", 1);
+    if (rows && side == sp2::SIDE) {
+        if (note_kernel("stem_pool_f16<rows,f32in>")) return METRO_OK;
+        static PerDeviceInt done;
+        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(stem_pool_rows_kernel), sp2::LDS_BYTES, done, "stem_pool_f16<rows>")) return st;
+        hipLaunchKernelGGL(stem_pool_rows_kernel, dim3(n * (sp2::PS / sp2::PY)), dim3(sp2::NT), sp2::LDS_BYTES, stream, a);
+        return launch_status("stem_pool_f16<rows>");
+    }
     static const int split = sp_env_int("METRO_STEM_RAW_SPLIT", 2);
     if (split == 1) return launch_sp<1, true>(a, stream);
     return launch_sp<2, true>(a, stream);
