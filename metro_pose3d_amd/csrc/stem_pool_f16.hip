@@ -355,13 +355,15 @@ constexpr int NWR = 16;                       // window ring rows (a conv row us
 constexpr int SROW = SIDE * 12;               // fp32 crop row: 3072 bytes = 3 LDS-DMA instructions
 constexpr int NSR = 8;                        // staging ring rows: 3 conv rows of lead (6 crop rows in flight) + 2 being cast
 constexpr int LEAD = 3;
-constexpr int OUT_BYTES = PS * 128;           // pooled row tile [64 X][64 channels] fp16
-constexpr int EDGE_BYTES = NW * 128;          // per pooled row: the edge column of every x-tile [64 channels] fp16
+constexpr int OUT_PITCH = 160;                // pooled row tile [64 X][64 channels] fp16, rows 40 banks apart: the 4-byte writes of
+                                              // the even lanes (column X) and the odd lanes (column X + 1) of a wave half never collide
+constexpr int OUT_BYTES = PS * OUT_PITCH;
+constexpr int EDGE_BYTES = (NW + 1) * 128;    // the edge column of every x-tile [64 channels] fp16, and a row of -inf (no edge to fold)
 constexpr int WIN_OFF = 0;
 constexpr int STG_OFF = WIN_OFF + NWR * WROW;
 constexpr int OUT_OFF = STG_OFF + NSR * SROW;
-constexpr int EDGE_OFF = OUT_OFF + 2 * OUT_BYTES;
-constexpr int LDS_BYTES = EDGE_OFF + 2 * EDGE_BYTES;      // 75 776: two blocks per CU
+constexpr int EDGE_OFF = OUT_OFF + OUT_BYTES;
+constexpr int LDS_BYTES = EDGE_OFF + EDGE_BYTES;          // 69 120: two blocks per CU
 }  // namespace sp2
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -403,21 +405,6 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
     const int Y0 = band * PY;
     const int ylo = Y0 == 0 ? 0 : 2 * Y0 - 1, yhi = 2 * Y0 + 2 * PY - 1;      // conv rows of the band (row -1 is the pool's zero row)
 
-    // ---- launch-resident weights as B fragments: both 32-channel tiles, 14 k-steps; the per-lane bias of its two channels ----
-    half8_t wf[2][KK];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
-            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(i * 32 + n) * 224 + kk * 16 + hh * 8);
-    float bias_l[2] = {a.bias[n], a.bias[32 + n]};
-    // every ordinary load is waited for HERE: a compiler-placed wait at the first use inside the row loop would be a vmcnt(0) per row
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) asm volatile("" : "+v"(wf[i][kk]));
-    asm volatile("" : "+v"(bias_l[0]), "+v"(bias_l[1]));
-
     const float* crop = a.img_f32 + (size_t)img * SIDE * SIDE * 3;
     // crop row i (clamped: rows outside the crop are cast to zeros whatever arrived) -> staging slot i & 7: waves 0-2 a KiB each
     auto issue_row = [&](int i) {
@@ -430,15 +417,84 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
             sp_dma16(src, __builtin_amdgcn_readfirstlane(smem_base + STG_OFF + (i & (NSR - 1)) * SROW + wave * 1024));
         }
     };
-    // window row p (bordered: crop row p - 3) from its staging slot: thread = pixel
-    auto cast_row = [&](int p) {
+    // window row p (bordered: crop row p - 3) from its staging slot: thread = pixel.  Read and write are separate steps: the steady
+    // state reads at the top of an iteration and writes at its end (an LDS latency and a half otherwise sit on the critical path)
+    auto cast_read = [&](int p, float (&v)[3]) {
         const int i = p - 3;
         const float* s3 = reinterpret_cast<const float*>(smem + STG_OFF + (i & (NSR - 1)) * SROW) + tid * 3;
         const bool ok = (unsigned)i < (unsigned)SIDE;
-        const float r = s3[0], g = s3[1], b = s3[2];
-        half4_t v = {(half_t)(ok ? r : 0.f), (half_t)(ok ? g : 0.f), (half_t)(ok ? b : 0.f), (half_t)0};
-        *reinterpret_cast<half4_t*>(smem + WIN_OFF + (p & (NWR - 1)) * WROW + (tid + 3) * 8) = v;
+        const float r = s3[0], g = s3[1], b = s3[2];       // read whatever the slot holds (no branch: a branch is a wait per read)
+        v[0] = ok ? r : 0.f; v[1] = ok ? g : 0.f; v[2] = ok ? b : 0.f;
     };
+    auto cast_write = [&](int p, const float (&v)[3]) {
+        half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)0};
+        *reinterpret_cast<half4_t*>(smem + WIN_OFF + (p & (NWR - 1)) * WROW + (tid + 3) * 8) = h;
+    };
+    auto cast_row = [&](int p) {
+        float v[3];
+        cast_read(p, v);
+        cast_write(p, v);
+    };
+    // group j = the two window rows 2j + 9, 2j + 10 that conv row j + 2 adds to conv row j + 1's (crop rows 2j + 6, 2j + 7)
+    auto issue_group = [&](int j) { issue_row(2 * j + 6); issue_row(2 * j + 7); };
+    auto cast_group = [&](int j) {
+#ifdef METRO_DBG_SP2_NO_CAST
+        if (a.n < 0)
+#endif
+        {
+            cast_row(2 * j + 9);
+            cast_row(2 * j + 10);
+        }
+    };
+
+    auto cast_group_read = [&](int j, float (&v)[2][3]) {
+#ifdef METRO_DBG_SP2_NO_CAST
+        if (a.n < 0)
+#endif
+        {
+            cast_read(2 * j + 9, v[0]);
+            cast_read(2 * j + 10, v[1]);
+        }
+    };
+    auto cast_group_write = [&](int j, const float (&v)[2][3]) {
+#ifdef METRO_DBG_SP2_NO_CAST
+        if (a.n < 0)
+#endif
+        {
+            cast_write(2 * j + 9, v[0]);
+            cast_write(2 * j + 10, v[1]);
+        }
+    };
+
+    // ---- pipeline fill, part 1: the seven window rows of the band's first conv row are requested; the weights meanwhile ----
+    const int i0 = 2 * ylo - 3;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) issue_row(i0 + r);
+    // launch-resident weights as B fragments: both 32-channel tiles, 14 k-steps; the per-lane bias of its two channels
+    half8_t wf[2][KK];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(i * 32 + n) * 224 + kk * 16 + hh * 8);
+    float bias_l[2] = {a.bias[n], a.bias[32 + n]};
+    // zero window (the borders stay zero: the cast only writes the 256 interior pixels of a row); the -inf row of the edge table
+    for (int i = tid; i < NWR * WROW / 16; i += NT) reinterpret_cast<uint4*>(smem + WIN_OFF)[i] = make_uint4(0, 0, 0, 0);
+    if (tid < 32) reinterpret_cast<unsigned*>(smem + EDGE_OFF + NW * 128)[tid] = 0xfc00fc00u;
+    sp_wait_vm<0>();
+    // every ordinary load is waited for HERE: a compiler-placed wait at the first use inside the row loop would be a vmcnt(0) per row
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) asm volatile("" : "+v"(wf[i][kk]));
+    asm volatile("" : "+v"(bias_l[0]), "+v"(bias_l[1]));
+    sp_barrier();
+#pragma unroll
+    for (int r = 0; r < 7; ++r) cast_row(2 * ylo + r);
+    sp_barrier();            // the staging slots are free again
+    // part 2: the groups of the pre-iteration and of the first three iterations (eight crop rows: every staging slot)
+#pragma unroll
+    for (int j = -1; j < LEAD; ++j) issue_group(ylo + j);
 
     // pooling state per channel tile: packed pairs (X = 2g, 2g + 1) per quad q; the edge column (its last O) likewise
     half2_t carry[2][4], mid[2][4], ecarry[2], emid[2];
@@ -450,162 +506,214 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
         ecarry[i] = zero2; emid[i] = zero2;
     }
     const unsigned lane_win = (unsigned)(512 * wave + 16 * n + 16 * hh);      // byte of the lane's pixel pair inside a window row
+    // pooled tile: quad q's columns X = 16 w + 4 q + 2 h' (even lanes), X + 1 (odd lanes), channels (n & ~1, + 1) of tile i at + 64 i
+    const unsigned out_lane = (unsigned)(OUT_OFF + (16 * wave + 2 * hh + (n & 1)) * OUT_PITCH + (n & ~1) * 2);
+    const unsigned out_sel = (n & 1) ? 0x03020706u : 0x05040100u;             // (other.hi, mine.hi) / (mine.lo, other.lo)
+    // quad -1 is the left x-tile's (its O is folded in by the store phase: -inf here) or, for x-tile 0, the pool's zero column
+    half2_t left;
+    left[0] = (half_t)0;
+    left[1] = wave == 0 ? (half_t)0 : (half_t)-INFINITY;
 
-    // ---- pipeline fill: the seven window rows of the band's first conv row, then the requests of the first three iterations ----
-    {
-        const int i0 = 2 * ylo - 3;
+    // conv row y: 14 k-steps, pixel fragments straight from the window (tap row kk >> 1, pixels 4 (kk & 1) + 2 h' ...)
+    auto conv_row = [&](floatx16 (&acc)[2], int y) {
 #pragma unroll
-        for (int r = 0; r < 7; ++r) issue_row(i0 + r);
-        // zero window meanwhile (the borders stay zero: the cast only writes the 256 interior pixels of a row)
-        for (int i = tid; i < NWR * WROW / 16; i += NT) reinterpret_cast<uint4*>(smem + WIN_OFF)[i] = make_uint4(0, 0, 0, 0);
-        sp_wait_vm<0>();
-        sp_barrier();
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 7; ++r) cast_row(2 * ylo + r);
-        sp_barrier();            // the staging slots are free again
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 #pragma unroll
-        for (int j = 0; j < LEAD; ++j) {
-            issue_row(2 * (ylo + j) + 7 - 3);
-            issue_row(2 * (ylo + j) + 8 - 3);
-        }
-    }
-    // One iteration per conv row y: request of the crop rows that iteration y + 3 casts, conv + pooling of row y, cast of the window
-    // rows 2y + 7, 2y + 8 (conv row y + 1's new rows).
-    for (int y = ylo; y <= yhi; ++y) {
-        // the crop rows cast in this iteration were requested three iterations ago: two iterations of requests (2 each) are
-        // younger.  The pooled-row stores in between are not counted: requests land in order among themselves, so "at most 4
-        // operations outstanding" implies these two have landed whatever the stores do
-        if (wave < 3) sp_wait_vm<4>();
-        sp_barrier();            // ... and everybody's share has landed; conv row y - 1 is done with window rows 2y - 2, 2y - 1
-        // ---- store phase: the pooled row finished in the last iteration ----
-        {
-            const int yp = y - 1;
-            if (yp >= ylo && (yp & 1) && yp != 2 * Y0 - 1) {
-                const int Y = (yp - 1) >> 1;
-                const char* ot = smem + OUT_OFF + (Y & 1) * OUT_BYTES;
-                const char* et = smem + EDGE_OFF + (Y & 1) * EDGE_BYTES;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int c = tid + r * NT;
-                    const int X = c >> 3, c8 = c & 7;
-                    half8_t v = *reinterpret_cast<const half8_t*>(ot + X * 128 + c8 * 16);
-                    if ((X & 15) == 0 && X > 0)       // O of the left x-tile's last column, pooled over the same three rows
-                        v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t*>(et + ((X >> 4) - 1) * 128 + c8 * 16));
-                    store_out16<1>(a.out + (((size_t)img * PS + Y) * PS + X) * 64 + c8 * 8, *reinterpret_cast<const uint4*>(&v));
-                }
-            }
-        }
-        issue_row(2 * (y + LEAD) + 7 - 3);
-        issue_row(2 * (y + LEAD) + 8 - 3);
-
-        {
-            // ---- conv row y: 14 k-steps, pixel fragments straight from the window (tap row kk >> 1, pixels 4 (kk & 1) + 2 h' ...) ----
-            floatx16 acc[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-                const int slot = (2 * y + (kk >> 1)) & (NWR - 1);
-                const half8_t pf = *reinterpret_cast<const half8_t*>(smem + WIN_OFF + slot * WROW + lane_win + (kk & 1) * 32);
+        for (int kk = 0; kk < KK; ++kk) {
+            const int slot = (2 * y + (kk >> 1)) & (NWR - 1);
+            const half8_t pf = *reinterpret_cast<const half8_t*>(smem + WIN_OFF + slot * WROW + lane_win + (kk & 1) * 32);
 #ifdef METRO_DBG_SP2_NO_MFMA      // timing experiments only (tools/build_dbg_variants.sh)
-                acc[0][kk] += (float)pf[0] * (float)wf[0][kk][0];
-                acc[1][kk] += (float)pf[1] * (float)wf[1][kk][1];
+            acc[0][kk] += (float)pf[0] * (float)wf[0][kk][0];
+            acc[1][kk] += (float)pf[1] * (float)wf[1][kk][1];
 #else
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, wf[0][kk], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, wf[1][kk], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, wf[0][kk], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, wf[1][kk], acc[1], 0, 0, 0);
 #endif
-            }
-#ifdef METRO_DBG_SP2_NO_POOL
-            if (acc[0][0] + acc[1][1] + acc[0][5] + acc[1][9] == 12345.f) a.out[tid] = (half_t)1;
-            if (a.n < 0)
-#endif
-            {
-            // ---- bias, fp16 (the value the reference's conv stores), horizontal 3-max, rolling vertical 3-max ----
-            const bool halo = y == 2 * Y0 - 1;              // the row above the band: only feeds the carry
-            const bool odd = y & 1;
-            half2_t P0[2][4], P1[2][4], R[2][4];             // (E[2g], O[2g]), (E[2g+1], O[2g+1]) per quad; the other half's P1
+        }
+    };
+    // bias, fp16 (the value the reference's conv stores) and the horizontal 3-max of a conv row: branch-free, so that it can sit in
+    // the shadow of the next row's MFMAs.  hp[i][q] = pooled columns (2g, 2g + 1) of channel tile i; eh[i].hi = the tile's last O
+    auto hmax_row = [&](const floatx16 (&acc)[2], half2_t (&hp)[2][4], half2_t (&eh)[2]) {
+        half2_t P0[2][4], P1[2][4], R[2][4];             // (E[2g], O[2g]), (E[2g+1], O[2g+1]) per quad; the other half's P1
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                P0[i][q][0] = (half_t)(acc[i][4 * q + 0] + bias_l[i]);
+                P0[i][q][1] = (half_t)(acc[i][4 * q + 1] + bias_l[i]);
+                P1[i][q][0] = (half_t)(acc[i][4 * q + 2] + bias_l[i]);
+                P1[i][q][1] = (half_t)(acc[i][4 * q + 3] + bias_l[i]);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R[i][q] = sp2_xchg32(P1[i][q]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // O[2g - 1] (the high half of): lane half 1 <- half 0's quad q; half 0 <- half 1's quad q - 1
+                const half2_t tsrc = hh ? R[i][q] : (q == 0 ? left : R[i][q > 0 ? q - 1 : 0]);
+                const half2_t A = sp2_max_pair_hi(P0[i][q]);         // (max(E0, O0), O0)
+                const half2_t C = sp2_max_pair_both(P1[i][q]);       // (max(E1, O1), same)
+                hp[i][q] = sp2_max(A, sp2_hi_lo(tsrc, C));           // (max(T, E0, O0), max(O0, E1, O1))
+            }
+            eh[i] = R[i][3];                              // lane half 0 holds half 1's quad 3 after the exchange
+        }
+    };
+    // rolling vertical 3-max; a finished pooled row goes to its LDS tile
+    auto vmax_row = [&](const half2_t (&hp)[2][4], const half2_t (&eh)[2], int y) {
+        const bool halo = y == 2 * Y0 - 1;              // the row above the band: only feeds the carry
+        const bool odd = y & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (halo) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) carry[i][q] = hp[i][q];
+                ecarry[i] = eh[i];
+            } else if (!odd) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mid[i][q] = hp[i][q];
+                emid[i] = eh[i];
+            } else {
+                // lane n holds (X, X + 1) of channel n: the lane pair (n, n ^ 1) swaps one column so that the even lane writes
+                // column X of channels (n, n + 1) and the odd lane column X + 1 of (n - 1, n): one 4-byte write per quad
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    P0[i][q][0] = (half_t)(acc[i][4 * q + 0] + bias_l[i]);
-                    P0[i][q][1] = (half_t)(acc[i][4 * q + 1] + bias_l[i]);
-                    P1[i][q][0] = (half_t)(acc[i][4 * q + 2] + bias_l[i]);
-                    P1[i][q][1] = (half_t)(acc[i][4 * q + 3] + bias_l[i]);
+                    const half2_t pooled = sp2_max(sp2_max(carry[i][q], mid[i][q]), hp[i][q]);
+                    const unsigned mine = __builtin_bit_cast(unsigned, pooled);
+                    const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+                    *reinterpret_cast<unsigned*>(smem + out_lane + q * 4 * OUT_PITCH + i * 64) = __builtin_amdgcn_perm(other, mine, out_sel);
+                    carry[i][q] = hp[i][q];
                 }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) R[i][q] = sp2_xchg32(P1[i][q]);
-            // quad -1 is the left x-tile's (its O is folded in by the store phase: -inf here) or, for x-tile 0, the pool's zero column
-            half2_t left;
-            left[0] = (half_t)0;
-            left[1] = wave == 0 ? (half_t)0 : (half_t)-INFINITY;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                half2_t hp[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    // O[2g - 1] (the high half of): lane half 1 <- half 0's quad q; half 0 <- half 1's quad q - 1
-                    const half2_t tsrc = hh ? R[i][q] : (q == 0 ? left : R[i][q > 0 ? q - 1 : 0]);
-                    const half2_t A = sp2_max_pair_hi(P0[i][q]);         // (max(E0, O0), O0)
-                    const half2_t C = sp2_max_pair_both(P1[i][q]);       // (max(E1, O1), same)
-                    hp[q] = sp2_max(A, sp2_hi_lo(tsrc, C));              // (max(T, E0, O0), max(O0, E1, O1))
-                }
-                half2_t eh = R[i][3];                         // its high half: the tile's last O (lane half 0 holds half 1's quad 3)
-                if (halo) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) carry[i][q] = hp[q];
-                    ecarry[i] = eh;
-                } else if (!odd) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) mid[i][q] = hp[q];
-                    emid[i] = eh;
-                } else {
-                    const int Y = (y - 1) >> 1;
-                    char* ot = smem + OUT_OFF + (Y & 1) * OUT_BYTES;
-                    char* et = smem + EDGE_OFF + (Y & 1) * EDGE_BYTES;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const half2_t pooled = sp2_max(sp2_max(carry[i][q], mid[i][q]), hp[q]);
-                        const int X = 16 * wave + 2 * (2 * q + hh);
-                        *reinterpret_cast<half_t*>(ot + X * 128 + (i * 32 + n) * 2) = pooled[0];
-                        *reinterpret_cast<half_t*>(ot + (X + 1) * 128 + (i * 32 + n) * 2) = pooled[1];
-                        carry[i][q] = hp[q];
-                    }
-                    const half2_t ep = sp2_max(sp2_max(ecarry[i], emid[i]), eh);
-                    if (hh == 0) *reinterpret_cast<half_t*>(et + wave * 128 + (i * 32 + n) * 2) = ep[1];
-                    ecarry[i] = eh;
-                }
-            }
+                const half2_t ep = sp2_max(sp2_max(ecarry[i], emid[i]), eh[i]);
+                if (hh == 0) *reinterpret_cast<half_t*>(smem + EDGE_OFF + wave * 128 + (i * 32 + n) * 2) = ep[1];
+                ecarry[i] = eh[i];
             }
         }
-        // ---- cast the window rows of conv row y + 1 (their crop rows landed before this iteration's barrier) ----
-#ifdef METRO_DBG_SP2_NO_CAST
-        if (a.n < 0)
-#endif
-        {
-            cast_row(2 * y + 7);
-            cast_row(2 * y + 8);
-        }
-    }
-    sp_barrier();
-    {   // the band's last pooled row
-        const int Y = (yhi - 1) >> 1;
-        const char* ot = smem + OUT_OFF + (Y & 1) * OUT_BYTES;
-        const char* et = smem + EDGE_OFF + (Y & 1) * EDGE_BYTES;
+    };
+    // the pooled row Y out of its LDS tile: 16 bytes per lane, the left x-tile's edge folded into column 16 w.  Read at the top of
+    // an iteration (the tile is rewritten by the iteration after), stored after the conv row
+    auto store_read = [&](half8_t (&v)[2]) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int c = tid + r * NT;
             const int X = c >> 3, c8 = c & 7;
-            half8_t v = *reinterpret_cast<const half8_t*>(ot + X * 128 + c8 * 16);
-            if ((X & 15) == 0 && X > 0)
-                v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t*>(et + ((X >> 4) - 1) * 128 + c8 * 16));
-            store_out16<1>(a.out + (((size_t)img * PS + Y) * PS + X) * 64 + c8 * 8, *reinterpret_cast<const uint4*>(&v));
+            const bool fold = (X & 15) == 0 && X > 0;       // O of the left x-tile's last column, pooled over the same three rows
+            typedef half2_t half2x4_t[4];
+            half2x4_t t, e;
+            *reinterpret_cast<uint4*>(&t) = *reinterpret_cast<const uint4*>(smem + OUT_OFF + X * OUT_PITCH + c8 * 16);
+            *reinterpret_cast<uint4*>(&e) = *reinterpret_cast<const uint4*>(smem + EDGE_OFF + (fold ? (X >> 4) - 1 : NW) * 128 + c8 * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = sp2_max(t[k], e[k]);
+            v[r] = *reinterpret_cast<const half8_t*>(&t);
+        }
+    };
+    auto store_write = [&](int Y, const half8_t (&v)[2]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int c = tid + r * NT;
+            const int X = c >> 3, c8 = c & 7;
+            store_out16<1>(a.out + (((size_t)img * PS + Y) * PS + X) * 64 + c8 * 8, *reinterpret_cast<const uint4*>(&v[r]));
+        }
+    };
+#ifdef METRO_DBG_SP2_CLOCK      // timing experiment: s_memtime at six points of every iteration, summed per interval (wave 0 of block 1)
+    long long clk_sum[6] = {0, 0, 0, 0, 0, 0}, clk_prev = 0, clk_start = __builtin_readcyclecounter();
+    const long long rt_start = __builtin_amdgcn_s_memrealtime();
+#define SP2_CLK(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); if (i) clk_sum[i] += t_ - clk_prev; clk_prev = t_; } while (0)
+#else
+#define SP2_CLK(i) do { } while (0)
+#endif
+    // ---- pre-iteration: the window rows 2 ylo + 7, + 8 (conv row ylo + 1's); conv row ylo ----
+    floatx16 accA[2], accB[2];
+    if (wave < 3) sp_wait_vm<6>();
+    sp_barrier();
+    cast_group(ylo - 1);
+    conv_row(accA, ylo);
+    // One iteration per conv row y: request of the crop rows that iteration y + 3 casts; conv row y + 1 (its window rows were cast
+    // an iteration ago) with the pooling of row y in the shadow of its MFMAs; cast of the window rows 2y + 9, 2y + 10.
+    auto iteration = [&](auto more_c, floatx16 (&cur)[2], floatx16 (&nxt)[2], int y) {
+        // the crop rows cast in this iteration were requested three iterations ago: two iterations of requests (2 each) are
+        // younger.  The pooled-row stores in between are not counted: requests land in order among themselves, so "at most 4
+        // operations outstanding" implies these two have landed whatever the stores do
+        SP2_CLK(0);
+        if (wave < 3) sp_wait_vm<4>();
+        sp_barrier();            // ... and everybody's share has landed; conv row y's window rows 2y, 2y + 1 are free
+        SP2_CLK(1);
+        const int yp = y - 1;
+        const bool storing = yp >= ylo && (yp & 1) && yp != 2 * Y0 - 1;       // a pooled row was finished in the last iteration
+        half8_t sv[2];
+        float cv[2][3];
+        store_read(sv);          // (whatever the tile holds when there is nothing to store: a branch would be a wait per read)
+        cast_group_read(y, cv);
+        issue_group(y + LEAD);
+        half2_t hp[2][4], eh[2];
+        SP2_CLK(2);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(more_c)::value) conv_row(nxt, y + 1);
+#ifdef METRO_DBG_SP2_NO_POOL
+        if (cur[0][0] + cur[1][1] + cur[0][5] + cur[1][9] == 12345.f) a.out[tid] = (half_t)1;
+#else
+        hmax_row(cur, hp, eh);
+#endif
+        if constexpr (decltype(more_c)::value) {
+            // the emitted order: fragment reads four k-steps ahead, then per MFMA three of the pooling's VALU operations and an
+            // LDS operation (fragment read / exchange)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int m = 0; m < 2 * KK; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SP2_CLK(3);
+        if (storing) store_write((yp - 1) >> 1, sv);
+        cast_group_write(y, cv);
+        SP2_CLK(4);
+#ifndef METRO_DBG_SP2_NO_POOL
+        vmax_row(hp, eh, y);
+#endif
+        SP2_CLK(5);
+    };
+    {
+        using Yes = std::integral_constant<bool, true>;
+        using No = std::integral_constant<bool, false>;
+        int y = ylo;
+        for (; y + 1 < yhi; y += 2) {
+            iteration(Yes{}, accA, accB, y);
+            iteration(Yes{}, accB, accA, y + 1);
+        }
+        if (y == yhi) {
+            iteration(No{}, accA, accB, y);
+        } else {
+            iteration(Yes{}, accA, accB, y);
+            iteration(No{}, accB, accA, y + 1);
         }
     }
+    sp_barrier();
+    {
+        half8_t sv[2];
+        store_read(sv);
+        store_write((yhi - 1) >> 1, sv);       // the band's last pooled row
+    }
+#ifdef METRO_DBG_SP2_CLOCK
+    if (tid == 0) {      // per block: start, end (100 MHz wall clock), HW_ID, XCC_ID -- behind the first 64 bytes
+        long long* blk = reinterpret_cast<long long*>(a.out) + 8 + blockIdx.x * 4;
+        blk[0] = rt_start; blk[1] = __builtin_amdgcn_s_memrealtime();
+        blk[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); blk[3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+    }
+    if (blockIdx.x == 1 && tid == 0) {
+        long long* dbg = reinterpret_cast<long long*>(a.out);
+        for (int i = 0; i < 6; ++i) dbg[i] = clk_sum[i];
+        dbg[6] = __builtin_readcyclecounter() - clk_start;
+        dbg[7] = yhi - ylo + 1;
+    }
+#endif
+#undef SP2_CLK
 }
 
 static int sp_env_int(const char* name, int dflt) { return tuning_knob(name, dflt); }
@@ -655,8 +763,10 @@ int launch_stem_pool_f32in(const float* images, const void* w, const float* bias
     static const int rows = sp_env_int("METRO_STEM_ROWS", 1);
     if (rows && side == sp2::SIDE) {
         if (note_kernel("stem_pool_f16<rows,f32in>")) return METRO_OK;
-        static PerDeviceInt done;
-        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(stem_pool_rows_kernel), sp2::LDS_BYTES, done, "stem_pool_f16<rows>")) return st;
+        static PerDeviceInt cap;
+        int grid_cap = 0;
+        if (const int st = ensure_dyn_lds_and_grid_cap(reinterpret_cast<const void*>(stem_pool_rows_kernel), sp2::NT, sp2::LDS_BYTES, cap, "stem_pool_f16<rows>", 0, &grid_cap)) return st;
+        if (getenv("METRO_STEM_DEBUG")) fprintf(stderr, "stem rows: resident blocks on the device %d\n", grid_cap);
         hipLaunchKernelGGL(stem_pool_rows_kernel, dim3(n * (sp2::PS / sp2::PY)), dim3(sp2::NT), sp2::LDS_BYTES, stream, a);
         return launch_status("stem_pool_f16<rows>");
     }
