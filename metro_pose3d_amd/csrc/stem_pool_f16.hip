@@ -351,10 +351,9 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
 namespace sp2 {
 constexpr int SIDE = 256, PS = 64, PY = 8, NW = 4, NT = 256, KK = 14;      // crop side, pooled side, pooled rows per band
 constexpr int WROW = (SIDE + 8) * 8;          // bordered fp16 4-channel row: 2112 bytes
-constexpr int NWR = 16;                       // window ring rows (a conv row uses 7, the next one's 2 new rows are cast meanwhile)
+constexpr int NWR = 16;                       // window ring rows (a pooled row's two conv rows use 9, the next one's 4 new rows are cast meanwhile)
 constexpr int SROW = SIDE * 12;               // fp32 crop row: 3072 bytes = 3 LDS-DMA instructions
-constexpr int NSR = 8;                        // staging ring rows: 3 conv rows of lead (6 crop rows in flight) + 2 being cast
-constexpr int LEAD = 3;
+constexpr int NSR = 12;                       // staging ring rows: three groups of four (one being cast, two in flight)
 constexpr int OUT_PITCH = 160;                // pooled row tile [64 X][64 channels] fp16, rows 40 banks apart: the 4-byte writes of
                                               // the even lanes (column X) and the odd lanes (column X + 1) of a wave half never collide
 constexpr int OUT_BYTES = PS * OUT_PITCH;
@@ -363,7 +362,8 @@ constexpr int WIN_OFF = 0;
 constexpr int STG_OFF = WIN_OFF + NWR * WROW;
 constexpr int OUT_OFF = STG_OFF + NSR * SROW;
 constexpr int EDGE_OFF = OUT_OFF + OUT_BYTES;
-constexpr int LDS_BYTES = EDGE_OFF + EDGE_BYTES;          // 69 120: two blocks per CU
+constexpr int LDS_BYTES = EDGE_OFF + EDGE_BYTES;          // 81 536: two blocks per CU, to the byte
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
 }  // namespace sp2
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -403,73 +403,56 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
     const int n = lane & 31, hh = lane >> 5;
     const int img = blockIdx.x / (PS / PY), band = blockIdx.x % (PS / PY);
     const int Y0 = band * PY;
-    const int ylo = Y0 == 0 ? 0 : 2 * Y0 - 1, yhi = 2 * Y0 + 2 * PY - 1;      // conv rows of the band (row -1 is the pool's zero row)
 
     const float* crop = a.img_f32 + (size_t)img * SIDE * SIDE * 3;
-    // crop row i (clamped: rows outside the crop are cast to zeros whatever arrived) -> staging slot i & 7: waves 0-2 a KiB each
-    auto issue_row = [&](int i) {
+    // crop row i (clamped: rows outside the crop are cast to zeros whatever arrived) -> a staging slot: waves 0-2 a KiB each
+    auto issue_row = [&](int i, int slot) {
 #ifdef METRO_DBG_SP2_NO_DMA
         if (a.n < 0)
 #endif
         if (wave < 3) {
             const int ic = i < 0 ? 0 : i > SIDE - 1 ? SIDE - 1 : i;
             const float* src = crop + (size_t)ic * SIDE * 3 + wave * 256 + lane * 4;
-            sp_dma16(src, __builtin_amdgcn_readfirstlane(smem_base + STG_OFF + (i & (NSR - 1)) * SROW + wave * 1024));
+            sp_dma16(src, __builtin_amdgcn_readfirstlane(smem_base + STG_OFF + slot * SROW + wave * 1024));
         }
     };
-    // window row p (bordered: crop row p - 3) from its staging slot: thread = pixel.  Read and write are separate steps: the steady
-    // state reads at the top of an iteration and writes at its end (an LDS latency and a half otherwise sit on the critical path)
-    auto cast_read = [&](int p, float (&v)[3]) {
-        const int i = p - 3;
-        const float* s3 = reinterpret_cast<const float*>(smem + STG_OFF + (i & (NSR - 1)) * SROW) + tid * 3;
-        const bool ok = (unsigned)i < (unsigned)SIDE;
-        const float r = s3[0], g = s3[1], b = s3[2];       // read whatever the slot holds (no branch: a branch is a wait per read)
-        v[0] = ok ? r : 0.f; v[1] = ok ? g : 0.f; v[2] = ok ? b : 0.f;
+    // window row p (bordered: crop row p - 3) from a staging slot: thread = pixel.  Read and write are separate steps: the steady
+    // state reads at the top of an iteration and writes at its end (an LDS latency and a half otherwise sit on the critical path);
+    // no branch around a read (a branch is a wait per read)
+    auto cast_read = [&](int p, int slot, half4_t& v) {
+        const float* s3 = reinterpret_cast<const float*>(smem + STG_OFF + slot * SROW) + tid * 3;
+        const bool ok = (unsigned)(p - 3) < (unsigned)SIDE;
+        const float r = s3[0], g = s3[1], b = s3[2];
+        v = half4_t{(half_t)(ok ? r : 0.f), (half_t)(ok ? g : 0.f), (half_t)(ok ? b : 0.f), (half_t)0};
     };
-    auto cast_write = [&](int p, const float (&v)[3]) {
-        half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)0};
-        *reinterpret_cast<half4_t*>(smem + WIN_OFF + (p & (NWR - 1)) * WROW + (tid + 3) * 8) = h;
+    auto cast_write = [&](int p, const half4_t& v) {
+        *reinterpret_cast<half4_t*>(smem + WIN_OFF + (p & (NWR - 1)) * WROW + (tid + 3) * 8) = v;
     };
-    auto cast_row = [&](int p) {
-        float v[3];
-        cast_read(p, v);
-        cast_write(p, v);
-    };
-    // group j = the two window rows 2j + 9, 2j + 10 that conv row j + 2 adds to conv row j + 1's (crop rows 2j + 6, 2j + 7)
-    auto issue_group = [&](int j) { issue_row(2 * j + 6); issue_row(2 * j + 7); };
-    auto cast_group = [&](int j) {
-#ifdef METRO_DBG_SP2_NO_CAST
-        if (a.n < 0)
-#endif
-        {
-            cast_row(2 * j + 9);
-            cast_row(2 * j + 10);
-        }
-    };
-
-    auto cast_group_read = [&](int j, float (&v)[2][3]) {
-#ifdef METRO_DBG_SP2_NO_CAST
-        if (a.n < 0)
-#endif
-        {
-            cast_read(2 * j + 9, v[0]);
-            cast_read(2 * j + 10, v[1]);
-        }
-    };
-    auto cast_group_write = [&](int j, const float (&v)[2][3]) {
-#ifdef METRO_DBG_SP2_NO_CAST
-        if (a.n < 0)
-#endif
-        {
-            cast_write(2 * j + 9, v[0]);
-            cast_write(2 * j + 10, v[1]);
-        }
-    };
-
-    // ---- pipeline fill, part 1: the seven window rows of the band's first conv row are requested; the weights meanwhile ----
-    const int i0 = 2 * ylo - 3;
+    // group t = the four window rows 4 (Y0 + t) + 9 ... + 12 that pooled row Y0 + t + 1 adds to pooled row Y0 + t's; staging slots 4 (t % 3) ...
+    auto issue_group = [&](int t) {
 #pragma unroll
-    for (int r = 0; r < 7; ++r) issue_row(i0 + r);
+        for (int r = 0; r < 4; ++r) issue_row(4 * (Y0 + t) + 6 + r, (t % 3) * 4 + r);
+    };
+    auto cast_group_read = [&](int t, half4_t (&v)[4]) {
+#ifdef METRO_DBG_SP2_NO_CAST
+        if (a.n < 0)
+#endif
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cast_read(4 * (Y0 + t) + 9 + r, (t % 3) * 4 + r, v[r]);
+    };
+    auto cast_group_write = [&](int t, const half4_t (&v)[4]) {
+#ifdef METRO_DBG_SP2_NO_CAST
+        if (a.n < 0)
+#endif
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cast_write(4 * (Y0 + t) + 9 + r, v[r]);
+    };
+
+    // ---- pipeline fill, part 1: the eleven window rows 4 Y0 - 2 ... 4 Y0 + 8 (the conv row above the band and the first pooled row's
+    //      two) are requested; the weights meanwhile ----
+    const int plo = 4 * Y0 - 2;
+#pragma unroll
+    for (int r = 0; r < 11; ++r) issue_row(plo + r - 3, r);
     // launch-resident weights as B fragments: both 32-channel tiles, 14 k-steps; the per-lane bias of its two channels
     half8_t wf[2][KK];
 #pragma unroll
@@ -490,20 +473,23 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
     asm volatile("" : "+v"(bias_l[0]), "+v"(bias_l[1]));
     sp_barrier();
 #pragma unroll
-    for (int r = 0; r < 7; ++r) cast_row(2 * ylo + r);
-    sp_barrier();            // the staging slots are free again
-    // part 2: the groups of the pre-iteration and of the first three iterations (eight crop rows: every staging slot)
-#pragma unroll
-    for (int j = -1; j < LEAD; ++j) issue_group(ylo + j);
+    for (int r = 0; r < 11; ++r) {
+        half4_t v;
+        cast_read(plo + r, r, v);
+        cast_write(plo + r, v);
+    }
+    sp_barrier();            // the staging slots are free again, the window rows visible
+    issue_group(0);
+    issue_group(1);
 
     // pooling state per channel tile: packed pairs (X = 2g, 2g + 1) per quad q; the edge column (its last O) likewise
-    half2_t carry[2][4], mid[2][4], ecarry[2], emid[2];
+    half2_t carry[2][4], ecarry[2];
     const half2_t zero2 = {(half_t)0, (half_t)0};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { carry[i][q] = zero2; mid[i][q] = zero2; }
-        ecarry[i] = zero2; emid[i] = zero2;
+        for (int q = 0; q < 4; ++q) carry[i][q] = zero2;
+        ecarry[i] = zero2;
     }
     const unsigned lane_win = (unsigned)(512 * wave + 16 * n + 16 * hh);      // byte of the lane's pixel pair inside a window row
     // pooled tile: quad q's columns X = 16 w + 4 q + 2 h' (even lanes), X + 1 (odd lanes), channels (n & ~1, + 1) of tile i at + 64 i
@@ -515,27 +501,49 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
     left[1] = wave == 0 ? (half_t)0 : (half_t)-INFINITY;
 
     // conv row y: 14 k-steps, pixel fragments straight from the window (tap row kk >> 1, pixels 4 (kk & 1) + 2 h' ...)
-    auto conv_row = [&](floatx16 (&acc)[2], int y) {
+    auto conv_row = [&](floatx16 (&acc)[2], int y, auto pin_c) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        // fragments are read THREE k-steps ahead of their MFMAs (four buffers): an LDS read takes ~150 cycles, a k-step's two
+        // MFMAs 64 -- left to itself the compiler reads one step ahead and every MFMA pair waits
+        auto frag = [&](int kk) {
+            const int slot = (2 * y + (kk >> 1)) & (NWR - 1);
+            return *reinterpret_cast<const half8_t*>(smem + WIN_OFF + slot * WROW + lane_win + (kk & 1) * 32);
+        };
+        half8_t pf[4];
+        pf[0] = frag(0); pf[1] = frag(1); pf[2] = frag(2);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            const int slot = (2 * y + (kk >> 1)) & (NWR - 1);
-            const half8_t pf = *reinterpret_cast<const half8_t*>(smem + WIN_OFF + slot * WROW + lane_win + (kk & 1) * 32);
+            if (kk + 3 < KK) pf[(kk + 3) & 3] = frag(kk + 3);
+            asm volatile("" ::: "memory");          // the read stays ahead of this k-step's MFMAs
 #ifdef METRO_DBG_SP2_NO_MFMA      // timing experiments only (tools/build_dbg_variants.sh)
-            acc[0][kk] += (float)pf[0] * (float)wf[0][kk][0];
-            acc[1][kk] += (float)pf[1] * (float)wf[1][kk][1];
+            acc[0][kk] += (float)pf[kk & 3][0] * (float)wf[0][kk][0];
+            acc[1][kk] += (float)pf[kk & 3][1] * (float)wf[1][kk][1];
 #else
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, wf[0][kk], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, wf[1][kk], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[kk & 3], wf[0][kk], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[kk & 3], wf[1][kk], acc[1], 0, 0, 0);
 #endif
+        }
+        if constexpr (decltype(pin_c)::value) {      // on its own: the emitted order (with the pooling: pinned by the caller)
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // bias, fp16 (the value the reference's conv stores) and the horizontal 3-max of a conv row: branch-free, so that it can sit in
     // the shadow of the next row's MFMAs.  hp[i][q] = pooled columns (2g, 2g + 1) of channel tile i; eh[i].hi = the tile's last O
     auto hmax_row = [&](const floatx16 (&acc)[2], half2_t (&hp)[2][4], half2_t (&eh)[2]) {
+#ifdef METRO_DBG_SP2_NO_POOL
+        if (acc[0][0] + acc[1][1] + acc[0][5] + acc[1][9] == 12345.f) a.out[tid] = (half_t)1;
+        for (int i = 0; i < 2; ++i) { for (int q = 0; q < 4; ++q) hp[i][q] = zero2; eh[i] = zero2; }
+        return;
+#endif
         half2_t P0[2][4], P1[2][4], R[2][4];             // (E[2g], O[2g]), (E[2g+1], O[2g+1]) per quad; the other half's P1
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -563,39 +571,8 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
             eh[i] = R[i][3];                              // lane half 0 holds half 1's quad 3 after the exchange
         }
     };
-    // rolling vertical 3-max; a finished pooled row goes to its LDS tile
-    auto vmax_row = [&](const half2_t (&hp)[2][4], const half2_t (&eh)[2], int y) {
-        const bool halo = y == 2 * Y0 - 1;              // the row above the band: only feeds the carry
-        const bool odd = y & 1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (halo) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) carry[i][q] = hp[i][q];
-                ecarry[i] = eh[i];
-            } else if (!odd) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) mid[i][q] = hp[i][q];
-                emid[i] = eh[i];
-            } else {
-                // lane n holds (X, X + 1) of channel n: the lane pair (n, n ^ 1) swaps one column so that the even lane writes
-                // column X of channels (n, n + 1) and the odd lane column X + 1 of (n - 1, n): one 4-byte write per quad
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const half2_t pooled = sp2_max(sp2_max(carry[i][q], mid[i][q]), hp[i][q]);
-                    const unsigned mine = __builtin_bit_cast(unsigned, pooled);
-                    const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
-                    *reinterpret_cast<unsigned*>(smem + out_lane + q * 4 * OUT_PITCH + i * 64) = __builtin_amdgcn_perm(other, mine, out_sel);
-                    carry[i][q] = hp[i][q];
-                }
-                const half2_t ep = sp2_max(sp2_max(ecarry[i], emid[i]), eh[i]);
-                if (hh == 0) *reinterpret_cast<half_t*>(smem + EDGE_OFF + wave * 128 + (i * 32 + n) * 2) = ep[1];
-                ecarry[i] = eh[i];
-            }
-        }
-    };
-    // the pooled row Y out of its LDS tile: 16 bytes per lane, the left x-tile's edge folded into column 16 w.  Read at the top of
-    // an iteration (the tile is rewritten by the iteration after), stored after the conv row
+    // the pooled row out of its LDS tile: 16 bytes per lane, the left x-tile's edge folded into column 16 w.  Read at the top of
+    // an iteration (the tile is rewritten at the end of it), stored after the conv rows
     auto store_read = [&](half8_t (&v)[2]) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -619,6 +596,7 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
             store_out16<1>(a.out + (((size_t)img * PS + Y) * PS + X) * 64 + c8 * 8, *reinterpret_cast<const uint4*>(&v[r]));
         }
     };
+
 #ifdef METRO_DBG_SP2_CLOCK      // timing experiment: s_memtime at six points of every iteration, summed per interval (wave 0 of block 1)
     long long clk_sum[6] = {0, 0, 0, 0, 0, 0}, clk_prev = 0, clk_start = __builtin_readcyclecounter();
     const long long rt_start = __builtin_amdgcn_s_memrealtime();
@@ -626,79 +604,81 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
 #else
 #define SP2_CLK(i) do { } while (0)
 #endif
-    // ---- pre-iteration: the window rows 2 ylo + 7, + 8 (conv row ylo + 1's); conv row ylo ----
     floatx16 accA[2], accB[2];
-    if (wave < 3) sp_wait_vm<6>();
-    sp_barrier();
-    cast_group(ylo - 1);
-    conv_row(accA, ylo);
-    // One iteration per conv row y: request of the crop rows that iteration y + 3 casts; conv row y + 1 (its window rows were cast
-    // an iteration ago) with the pooling of row y in the shadow of its MFMAs; cast of the window rows 2y + 9, 2y + 10.
-    auto iteration = [&](auto more_c, floatx16 (&cur)[2], floatx16 (&nxt)[2], int y) {
-        // the crop rows cast in this iteration were requested three iterations ago: two iterations of requests (2 each) are
-        // younger.  The pooled-row stores in between are not counted: requests land in order among themselves, so "at most 4
-        // operations outstanding" implies these two have landed whatever the stores do
-        SP2_CLK(0);
-        if (wave < 3) sp_wait_vm<4>();
-        sp_barrier();            // ... and everybody's share has landed; conv row y's window rows 2y, 2y + 1 are free
-        SP2_CLK(1);
-        const int yp = y - 1;
-        const bool storing = yp >= ylo && (yp & 1) && yp != 2 * Y0 - 1;       // a pooled row was finished in the last iteration
-        half8_t sv[2];
-        float cv[2][3];
-        store_read(sv);          // (whatever the tile holds when there is nothing to store: a branch would be a wait per read)
-        cast_group_read(y, cv);
-        issue_group(y + LEAD);
+    // ---- the conv row above the band: only feeds the carry (band 0: the pool's zero row is the initial carry) ----
+    if (Y0 > 0) {
         half2_t hp[2][4], eh[2];
+        conv_row(accA, 2 * Y0 - 1, std::true_type{});
+        hmax_row(accA, hp, eh);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) carry[i][q] = hp[i][q];
+            ecarry[i] = eh[i];
+        }
+    }
+    // ---- one iteration per pooled row Y = Y0 + t: conv rows 2Y (accA) and 2Y + 1 (accB, with row 2Y's pooling in the shadow of its
+    //      MFMAs); request of the crop rows that iteration t + 2 casts; cast of the window rows 4Y + 9 ... 4Y + 12 ----
+    for (int t = 0; t < PY; ++t) {
+        const int Y = Y0 + t;
+        SP2_CLK(0);
+        // the crop rows cast in this iteration were requested two iterations ago: one iteration of requests (4) is younger.  The
+        // pooled-row stores in between are not counted: requests land in order among themselves, so "at most 4 operations
+        // outstanding" implies this group has landed whatever the stores do
+        if (wave < 3) sp_wait_vm<4>();
+        sp_barrier();            // ... and everybody's share has landed; the last pooled row's tile is complete
+        SP2_CLK(1);
+        half8_t sv[2];
+        half4_t cv[4];
+        store_read(sv);          // (whatever the tile holds in the first iteration: a branch would be a wait per read)
+        cast_group_read(t, cv);
+        issue_group(t + 2);
         SP2_CLK(2);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (decltype(more_c)::value) conv_row(nxt, y + 1);
-#ifdef METRO_DBG_SP2_NO_POOL
-        if (cur[0][0] + cur[1][1] + cur[0][5] + cur[1][9] == 12345.f) a.out[tid] = (half_t)1;
-#else
-        hmax_row(cur, hp, eh);
-#endif
-        if constexpr (decltype(more_c)::value) {
-            // the emitted order: fragment reads four k-steps ahead, then per MFMA three of the pooling's VALU operations and an
-            // LDS operation (fragment read / exchange)
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        conv_row(accA, 2 * Y, std::true_type{});
+        half2_t hpA[2][4], ehA[2], hpB[2][4], ehB[2];
+        conv_row(accB, 2 * Y + 1, std::false_type{});
+        hmax_row(accA, hpA, ehA);
+        // the emitted order: three fragment reads, then per MFMA four of the pooling's VALU operations and an LDS operation
+        // (fragment read / exchange)
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
-            for (int m = 0; m < 2 * KK; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
-            }
+        for (int m = 0; m < 2 * KK; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         SP2_CLK(3);
-        if (storing) store_write((yp - 1) >> 1, sv);
-        cast_group_write(y, cv);
+        hmax_row(accB, hpB, ehB);
+        if (t > 0) store_write(Y - 1, sv);
+        cast_group_write(t, cv);
         SP2_CLK(4);
+        // vertical 3-max; lane n holds (X, X + 1) of channel n: the lane pair (n, n ^ 1) swaps one column so that the even lane
+        // writes column X of channels (n, n + 1) and the odd lane column X + 1 of (n - 1, n): one 4-byte write per quad
 #ifndef METRO_DBG_SP2_NO_POOL
-        vmax_row(hp, eh, y);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const half2_t pooled = sp2_max(sp2_max(carry[i][q], hpA[i][q]), hpB[i][q]);
+                const unsigned mine = __builtin_bit_cast(unsigned, pooled);
+                const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+                *reinterpret_cast<unsigned*>(smem + out_lane + q * 4 * OUT_PITCH + i * 64) = __builtin_amdgcn_perm(other, mine, out_sel);
+                carry[i][q] = hpB[i][q];
+            }
+            const half2_t ep = sp2_max(sp2_max(ecarry[i], ehA[i]), ehB[i]);
+            if (hh == 0) *reinterpret_cast<half_t*>(smem + EDGE_OFF + wave * 128 + (i * 32 + n) * 2) = ep[1];
+            ecarry[i] = ehB[i];
+        }
 #endif
         SP2_CLK(5);
-    };
-    {
-        using Yes = std::integral_constant<bool, true>;
-        using No = std::integral_constant<bool, false>;
-        int y = ylo;
-        for (; y + 1 < yhi; y += 2) {
-            iteration(Yes{}, accA, accB, y);
-            iteration(Yes{}, accB, accA, y + 1);
-        }
-        if (y == yhi) {
-            iteration(No{}, accA, accB, y);
-        } else {
-            iteration(Yes{}, accA, accB, y);
-            iteration(No{}, accB, accA, y + 1);
-        }
     }
     sp_barrier();
     {
         half8_t sv[2];
         store_read(sv);
-        store_write((yhi - 1) >> 1, sv);       // the band's last pooled row
+        store_write(Y0 + PY - 1, sv);       // the band's last pooled row
     }
 #ifdef METRO_DBG_SP2_CLOCK
     if (tid == 0) {      // per block: start, end (100 MHz wall clock), HW_ID, XCC_ID -- behind the first 64 bytes
@@ -710,7 +690,7 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
         long long* dbg = reinterpret_cast<long long*>(a.out);
         for (int i = 0; i < 6; ++i) dbg[i] = clk_sum[i];
         dbg[6] = __builtin_readcyclecounter() - clk_start;
-        dbg[7] = yhi - ylo + 1;
+        dbg[7] = PY;
     }
 #endif
 #undef SP2_CLK

@@ -14,8 +14,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 d = out.view(-1)[:32].cpu().numpy().view(np.int64)
 rows = int(d[7])
-names = ['', 'wait+barrier', 'tile+staging reads, requests', 'conv(y+1)+hmax(y)', 'stores+window writes', 'vmax+tile writes']
-print(f'n={n}: block 1, wave 0: {rows} rows, {d[6]} cycles in the kernel; per iteration: ' +
+names = ['', 'wait+barrier', 'tile+staging reads, requests', 'conv(2Y), conv(2Y+1)+hmax(2Y)', 'hmax(2Y+1), stores, window writes', 'vmax+tile writes']
+print(f'n={n}: block 1, wave 0: {rows} pooled rows, {d[6]} cycles in the kernel; per iteration: ' +
       ', '.join(f'{names[i]} {d[i] / rows:.0f}' for i in range(1, 6)) + f'; sum {sum(d[1:6]) / rows:.0f}')
 
 nb = n * 8
