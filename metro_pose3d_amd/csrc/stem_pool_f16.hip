@@ -343,10 +343,16 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
 //   * block = 4 waves = the 4 x-tiles of a band of 8 pooled rows x the full width (no horizontal halo; one conv row of vertical halo:
 //     6 % recompute against 13 % + 10 % tile padding above: 32.0 GFLOP issued at batch 64 instead of 37.6); every wave all 64
 //     channels (112 VGPRs of weights; a pixel fragment is read once for both channel tiles);
-//   * the band is walked one conv row per barrier: the fp32 crop rows come by LDS-DMA into a staging ring three rows of conv ahead,
-//     are cast into the zero-bordered 4-channel fp16 window ring (architectures.py:29) one row of conv ahead;
-//   * pooled rows leave through an 8 KiB LDS tile ([X][channel], for 16-byte stores): 24 KB of LDS writes + reads per pooled row
-//     against 111 KB of conv tile traffic before.
+//   * the band is walked one POOLED row (two conv rows) per barrier; window row 4Y + j is tap row j of conv row 2Y and tap row j - 2
+//     of conv row 2Y + 1, so each pixel fragment is read once for both rows (18 LDS reads per 56 MFMAs, three ahead of their use);
+//   * the fp32 crop rows come by LDS-DMA into a staging ring two pooled rows ahead and are cast into the zero-bordered 4-channel
+//     fp16 window ring (architectures.py:29) one pooled row ahead (read at the top of an iteration, written at its end);
+//   * pooled rows leave through a 10 KiB LDS tile ([X][channel], 4-byte writes after a lane-pair swap, 16-byte reads and stores):
+//     20 KB of LDS writes + reads per pooled row against 111 KB of conv tile traffic before.
+// What it is bound by (tools/stem_knockouts.sh, tools/stem_clock.py, tools/stem_pmc.sh at batch 64): a wave's iteration is MFMAs
+// (1 800 cycles at full rate) + pooling (1 300) + tile / staging / window traffic and requests (1 400), one after the other -- 330
+// VALU instructions per 56 MFMAs do not fit the five issue slots an MFMA leaves, and the pooling of a row needs its accumulators
+// finished; two co-resident blocks overlap by a third (26 us each against 20 alone).  MFMA pipe busy 36 %.
 // Bit-identical to the kernel above (same k order per output, same fp16 rounding before the max).
 namespace sp2 {
 constexpr int SIDE = 256, PS = 64, PY = 8, NW = 4, NT = 256, KK = 14;      // crop side, pooled side, pooled rows per band
@@ -512,22 +518,26 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
             const int slot = (2 * y + (kk >> 1)) & (NWR - 1);
             return *reinterpret_cast<const half8_t*>(smem + WIN_OFF + slot * WROW + lane_win + (kk & 1) * 32);
         };
-        half8_t pf[4];
-        pf[0] = frag(0); pf[1] = frag(1); pf[2] = frag(2);
+#ifndef SP2_PF
+#define SP2_PF 4
+#endif
+        half8_t pf[SP2_PF];
+#pragma unroll
+        for (int kk = 0; kk < SP2_PF - 1; ++kk) pf[kk] = frag(kk);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            if (kk + 3 < KK) pf[(kk + 3) & 3] = frag(kk + 3);
+            if (kk + SP2_PF - 1 < KK) pf[(kk + SP2_PF - 1) % SP2_PF] = frag(kk + SP2_PF - 1);
             asm volatile("" ::: "memory");          // the read stays ahead of this k-step's MFMAs
 #ifdef METRO_DBG_SP2_NO_MFMA      // timing experiments only (tools/build_dbg_variants.sh)
-            acc[0][kk] += (float)pf[kk & 3][0] * (float)wf[0][kk][0];
-            acc[1][kk] += (float)pf[kk & 3][1] * (float)wf[1][kk][1];
+            acc[0][kk] += (float)pf[kk % SP2_PF][0] * (float)wf[0][kk][0];
+            acc[1][kk] += (float)pf[kk % SP2_PF][1] * (float)wf[1][kk][1];
 #else
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[kk & 3], wf[0][kk], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[kk & 3], wf[1][kk], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[kk % SP2_PF], wf[0][kk], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[kk % SP2_PF], wf[1][kk], acc[1], 0, 0, 0);
 #endif
         }
         if constexpr (decltype(pin_c)::value) {      // on its own: the emitted order (with the pooling: pinned by the caller)
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, SP2_PF - 1, 0);
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
@@ -535,6 +545,57 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    // Conv rows 2Y and 2Y + 1 together: window row 4Y + j is tap row j of the first and tap row j - 2 of the second, so each of its two
+    // fragments is read ONCE for both rows (18 reads instead of 28: the fragment reads are 70 % of the kernel's LDS traffic, and two
+    // co-resident blocks were bound by it); four independent accumulator chains.  The k order of every output is unchanged.
+    auto conv_pair = [&](floatx16 (&accA)[2], floatx16 (&accB)[2], int Y) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { accA[i][e] = 0.f; accB[i][e] = 0.f; }
+        auto frag = [&](int f) {          // fragment f = 2 j + half of window row 4Y + j
+            const int slot = (4 * Y + (f >> 1)) & (NWR - 1);
+            return *reinterpret_cast<const half8_t*>(smem + WIN_OFF + slot * WROW + lane_win + (f & 1) * 32);
+        };
+        half8_t pf[SP2_PF];
+#pragma unroll
+        for (int f = 0; f < SP2_PF - 1; ++f) pf[f] = frag(f);
+#pragma unroll
+        for (int f = 0; f < 18; ++f) {
+            if (f + SP2_PF - 1 < 18) pf[(f + SP2_PF - 1) % SP2_PF] = frag(f + SP2_PF - 1);
+#ifdef METRO_DBG_SP2_NO_MFMA      // timing experiments only (tools/build_dbg_variants.sh)
+            accA[0][f & 15] += (float)pf[f % SP2_PF][0] * (float)wf[0][f % KK][0];
+            accB[1][f & 15] += (float)pf[f % SP2_PF][1] * (float)wf[1][f % KK][1];
+#else
+            if (f < KK) {
+                accA[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[f % SP2_PF], wf[0][f < KK ? f : 0], accA[0], 0, 0, 0);
+                accA[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[f % SP2_PF], wf[1][f < KK ? f : 0], accA[1], 0, 0, 0);
+            }
+            if (f >= 4) {
+                accB[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[f % SP2_PF], wf[0][f >= 4 ? f - 4 : 0], accB[0], 0, 0, 0);
+                accB[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[f % SP2_PF], wf[1][f >= 4 ? f - 4 : 0], accB[1], 0, 0, 0);
+            }
+#endif
+        }
+        // the emitted order: fragment reads SP2_PF - 1 ahead of their MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, SP2_PF - 1, 0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {          // window rows 0, 1: the first conv row only
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int f = 4; f < KK; ++f) {         // rows 2 ... 6: both
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int f = KK; f < 18; ++f) {        // rows 7, 8: the second only
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
     // bias, fp16 (the value the reference's conv stores) and the horizontal 3-max of a conv row: branch-free, so that it can sit in
     // the shadow of the next row's MFMAs.  hp[i][q] = pooled columns (2g, 2g + 1) of channel tile i; eh[i].hi = the tile's last O
@@ -635,20 +696,9 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
         issue_group(t + 2);
         SP2_CLK(2);
         __builtin_amdgcn_sched_barrier(0);
-        conv_row(accA, 2 * Y, std::true_type{});
+        conv_pair(accA, accB, Y);
         half2_t hpA[2][4], ehA[2], hpB[2][4], ehB[2];
-        conv_row(accB, 2 * Y + 1, std::false_type{});
         hmax_row(accA, hpA, ehA);
-        // the emitted order: three fragment reads, then per MFMA four of the pooling's VALU operations and an LDS operation
-        // (fragment read / exchange)
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-        for (int m = 0; m < 2 * KK; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         SP2_CLK(3);
         hmax_row(accB, hpB, ehB);
         if (t > 0) store_write(Y - 1, sv);

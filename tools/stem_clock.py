@@ -27,3 +27,14 @@ print(f'blocks {nb}: start min/median/max {start.min():.1f}/{np.median(start):.1
       f'duration median {np.median(end - start):.1f} us; distinct CUs {len(set(cu.tolist()))}, blocks per CU max {np.bincount(np.unique(cu, return_inverse=True)[1]).max()}')
 late = start > 5
 print(f'blocks starting later than 5 us: {late.sum()}')
+pairs = {}
+for b, c in enumerate(cu.tolist()):
+    pairs.setdefault(c, []).append(b)
+ex = [v for v in pairs.values() if len(v) == 2][:12]
+print('co-resident block ids (first CUs):', ex)
+d = np.array([abs(v[1] - v[0]) for v in pairs.values() if len(v) == 2])
+if len(d): print('id distance of co-resident pairs: ', np.unique(d, return_counts=True))
+wid = blk[:, 2] & 15
+simd = (blk[:, 2] >> 4) & 3
+print('wave slot ids of wave 0 in blocks 0..7:', wid[:8].tolist(), ' in blocks 256..263:', wid[256:264].tolist() if nb > 263 else '', ' simd:', simd[:4].tolist(), simd[256:260].tolist() if nb > 263 else '')
+print('slot id histogram:', np.bincount(wid).tolist())
