@@ -362,7 +362,7 @@ __device__ __forceinline__ AccT sa_wave_sum(AccT v) {
 }
 
 template <typename AccT>
-__global__ __launch_bounds__(256) void softargmax_finalize_kernel(const AccT* __restrict__ partials,
+__global__ __launch_bounds__(1024) void softargmax_finalize_kernel(const AccT* __restrict__ partials,
                                                                   float* __restrict__ poses,
                                                                   SoftArgmaxArgs a, int slabs,
                                                                   float* __restrict__ coords01,
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void softargmax_finalize_kernel(const AccT* __
             mm[j][2] = z01 * (AccT)a.box_size_mm;
         }
     } else
-    for (int j = wave; j < nj; j += 4) {
+    for (int j = wave; j < nj; j += (int)(blockDim.x >> 6)) {      // many records per joint: a wave per joint (16 waves: one or two rounds)
         AccT M = (AccT)-INFINITY;
         for (int sl = lane; sl < slabs; sl += 64) {
             const AccT mv = partials[(((size_t)img * slabs + sl) * nj + j) * 5];
@@ -424,11 +424,13 @@ __global__ __launch_bounds__(256) void softargmax_finalize_kernel(const AccT* __
             M = other > M ? other : M;
         }
         AccT S = 0, SX = 0, SY = 0, SZ = 0;
+#pragma unroll 2
         for (int sl = lane; sl < slabs; sl += 64) {
             const AccT* r = partials + (((size_t)img * slabs + sl) * nj + j) * 5;
-            if (r[1] > 0) {
-                const AccT f = acc_exp<AccT>(r[0] - M);
-                S += r[1] * f; SX += r[2] * f; SY += r[3] * f; SZ += r[4] * f;
+            const AccT r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];      // all five before the test: one latency, not two
+            if (r1 > 0) {
+                const AccT f = acc_exp<AccT>(r0 - M);
+                S += r1 * f; SX += r2 * f; SY += r3 * f; SZ += r4 * f;
             } else bad = true;
         }
         S = sa_wave_sum(S); SX = sa_wave_sum(SX); SY = sa_wave_sum(SY); SZ = sa_wave_sum(SZ);
@@ -493,7 +495,7 @@ static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void
                        static_cast<AccT*>(partials), a.side, a.depth, a.n_joints_head, slabs);
     int st = launch_status("softargmax_partial");
     if (st) return st;
-    hipLaunchKernelGGL(softargmax_finalize_kernel<AccT>, dim3(a.n), dim3(256), 0, stream,
+    hipLaunchKernelGGL(softargmax_finalize_kernel<AccT>, dim3(a.n), dim3(slabs > 16 ? 1024 : 256), 0, stream,
                        static_cast<const AccT*>(partials), poses, a, slabs, coords01, status);
     return launch_status("softargmax_finalize");
 }
@@ -501,7 +503,7 @@ static int launch_softargmax_t(const void* logits, const SoftArgmaxArgs& a, void
 int launch_softargmax_finalize(const float* partials, const SoftArgmaxArgs& a, int slabs, float* poses_out,
                                hipStream_t stream, float* coords01_out, int32_t* status) {
     if (note_kernel("softargmax_finalize<acc32>")) return METRO_OK;
-    hipLaunchKernelGGL(softargmax_finalize_kernel<float>, dim3(a.n), dim3(256), 0, stream, partials, poses_out, a, slabs, coords01_out, status);
+    hipLaunchKernelGGL(softargmax_finalize_kernel<float>, dim3(a.n), dim3(slabs > 16 ? 1024 : 256), 0, stream, partials, poses_out, a, slabs, coords01_out, status);
     return launch_status("softargmax_finalize");
 }
 
