@@ -315,8 +315,10 @@ int  metro_softargmax(const void* d_logits, int32_t n, const MetroSpec* spec, in
 
 /* The volumetric head in ONE launch, as metro_forward runs it in f16 mode for heads of <= 160 channels (head_f16.hip):
  * postnorm BN + ReLU on the raw residual stream (reference resnet_v2.py:229), the 1x1 logits convolution + bias (:233-236,
- * fp32 accumulators, architectures.py:34), the per-joint softmax statistics of every 64-pixel slab from the on-chip logits
+ * fp32 accumulators, architectures.py:34), the per-joint softmax statistics of every 32-pixel slab from the on-chip logits
  * tile (volumetric.py:227-235, tfu.py:466-499), then the slab fold / mm decode / root-relative / gather of metro_softargmax.
+ * The kernel (tile of 256 / 128 / 64 pixels, K-parts per wave group) is chosen from the batch: results are reproducible for a
+ * given n, not bit-identical across n (the K-parts are added in a fixed order that depends on the tile).
  * d_x fp16 [n, side, side, c_in]; d_w fp16 [depth * J][c_in]; d_bias fp32; d_pro_scale / d_pro_shift fp16 [c_in];
  * d_partials: metro_head_f16_scratch_bytes(); d_logits_out: optional fp32 NHWC logits dump (NULL in the product path). */
 int64_t metro_head_f16_scratch_bytes(int32_t n, int32_t side, int32_t n_joints_head);

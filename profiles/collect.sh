@@ -37,5 +37,7 @@ if [ -z "$quick" ]; then
   rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $out/tcc/a -o $tag -- $B --steps 2 --warmup 1 > $out/pmc_tcc.log 2>&1 || echo "TCC pass failed"
   python profiles/pmc_table.py $out/tcc 1 > $out/${tag}_tcc_layers.tsv || true
 fi
+# the bench line attaches the traffic of THIS collection (bench.py reads profiles/*_pmc_traffic.json and checks the kernel hash)
+cp $out/${tag}*_pmc_traffic.json profiles/
 python bench.py --layer-report $out/${tag}_layers_hipevents.tsv > $out/${tag}_bench.json 2> $out/bench.err
 tail -1 $out/${tag}_bench.json | cut -c1-300
