@@ -307,10 +307,12 @@ def test_conv_f16_next_proj(lib, cuda, shape):
     assert torch.equal(o1, out) and torch.equal(o2, out2), 'in-launch projection shortcut vs the shortcut tensor of a separate launch'
 
 
-@pytest.mark.parametrize('n,side', [(2, 64), (3, 96), (9, 256)])
+@pytest.mark.parametrize('n,side', [(2, 64), (3, 96), (9, 256), (33, 256)])
 def test_stem_pool_f16(lib, cuda, n, side):
     """Stem 7x7/2 + zero-padded 3x3/2 max-pool in one launch against torch fp64 on the same fp16 operands
-    (reference resnet_v2.py:219-224, resnet_utils.py:138-185); 9 x 256^2 = more patches than resident blocks."""
+    (reference resnet_v2.py:219-224, resnet_utils.py:138-185); 9 x 256^2 = more patches than resident blocks.  At 256-pixel
+    crops the fp32-input entry runs stem_pool_rows_kernel (conv pixels as MFMA rows, the pool in registers; 33 crops = more
+    bands than a device holds): it must give the bits of the patch kernel -- same k order per output, one fp16 rounding."""
     rng = np.random.default_rng(n * 1000 + side)
     img = rng.uniform(-1, 1, (n, side, side, 3)).astype(np.float32)
     w = (rng.standard_normal((64, 7, 7, 3)) * np.sqrt(2.0 / 147)).astype(np.float16)      # [o][kh][kw][c]
