@@ -13,7 +13,7 @@ from tests import helpers as H
 
 lib = _lib.load()
 dev = torch.device('cuda', 0)
-for name, spec, n in (('C2 b64', ModelSpec(50, 16, 'h36m'), 64), ('C2 b256', ModelSpec(50, 16, 'h36m'), 256),
+for name, spec, n in (('C2 b64', ModelSpec(50, 16, 'h36m'), 64), ('C2 b256', ModelSpec(50, 16, 'h36m'), 256), ('C3 b256 J19', ModelSpec(50, 16, 'many19'), 256),
                       ('C4 b32', ModelSpec(101, 8, 'many19'), 32), ('C5 b16', ModelSpec(50, 4, 'h36m'), 16)):
     side, k, c = spec.heatmap_side, 2048, spec.n_head_channels
     g = torch.Generator(device=dev).manual_seed(1)
