@@ -11,7 +11,8 @@ same CLI flag `--model-path`.  Differences that follow from not being TensorFlow
   * N is free, as with the reference's `[None, 256, 256, 3]` placeholder (main.py:109-111): the call plans for the
     batch it is given -- one `metro_forward` for up to 256 crops, 256-crop chunks beyond.  Kernel dispatch depends on the
     crops per call (tile counts against 256 CUs: from 128 crops on the 3x3 layers take 512-pixel tiles, the head takes
-    256-pixel tiles once it has 256 of them), so results are not bit-stable ACROSS call sizes >= 128 (estimate_pose docstring);
+    128- / 256-pixel tiles once it has 256 of them), so results are not bit-stable ACROSS call sizes >= 128 at stride 16
+    (estimate_pose docstring);
   * one process per GPU under torch.distributed: the same call shards the batch by image and all-gathers the poses.
 Input contract (inference.py:17-18, main.py:109-110): float32 NHWC [N,256,256,3], RGB in [0,1].
 The arithmetic mode defaults to fp16, the reference's default compute dtype (options.py:73);
@@ -98,9 +99,10 @@ def estimate_pose(images_tensor, model_path, precision: Optional[str] = None, ch
     `shard=False` keeps the call local; `group` selects a process group.
 
     Results are NOT bit-stable across call sizes: kernel tile shapes follow the crops per call (the engine buckets of 8 / 64 /
-    256; from 128 crops per call on the 3x3 layers take 512-pixel tiles; the head takes 256-pixel tiles once n * S * S / 256 >= 256)
-    and every tile shape is another fp32 summation order.  Differences are rounding flips of the fp16 chain (tests/
-    test_gpu_forward.py), calls below 128 crops agree bit for bit with one another whatever their size.
+    256; from 128 crops per call on the 3x3 layers take 512-pixel tiles; the head takes 128- and then 256-pixel tiles once it has
+    256 of them: n * S * S / 128 >= 256, i.e. from 128 crops at stride 16, 32 at stride 8, 8 at stride 4) and every tile shape is
+    another fp32 summation order.  Differences are rounding flips of the fp16 chain (tests/test_gpu_forward.py); at stride 16
+    calls below 128 crops agree bit for bit with one another whatever their size.
 
     `check_finite` (default on; METRO_CHECK_FINITE=0 turns it off): after the forward, the finalize launch's non-finite screen
     is read back (one stream synchronisation per call, as the reference's blocking sess.run) and NonFiniteError is raised when
