@@ -707,6 +707,7 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
         // vertical 3-max; lane n holds (X, X + 1) of channel n: the lane pair (n, n ^ 1) swaps one column so that the even lane
         // writes column X of channels (n, n + 1) and the odd lane column X + 1 of (n - 1, n): one 4-byte write per quad
 #ifndef METRO_DBG_SP2_NO_POOL
+        sp_barrier();            // every wave has read the last pooled row out of the tile (at the top of this iteration)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
