@@ -26,9 +26,9 @@ if len(sys.argv) > 2:            # child: run one setting, dump the output
     print(f'{kid}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us  finite {np.isfinite(o.astype(np.float32)).all()}')
     sys.exit(0)
 n = sys.argv[1] if len(sys.argv) > 1 else '64'
-for rows in ('0', '1'):
+for rows in ('0', os.environ.get('STEM_AB_ROWS', '1')):
     env = dict(os.environ, METRO_STEM_ROWS=rows)
     print(subprocess.run([sys.executable, __file__, n, f'/tmp/stem_rows{rows}.npy'], env=env, capture_output=True, text=True).stdout.strip().split('\n')[-1])
-a, b = np.load('/tmp/stem_rows0.npy'), np.load('/tmp/stem_rows1.npy')
+a, b = np.load('/tmp/stem_rows0.npy'), np.load('/tmp/stem_rows%s.npy' % os.environ.get('STEM_AB_ROWS', '1'))
 diff = a != b
 print('same bits' if not diff.any() else f'DIFFER: {diff.sum()} of {diff.size}; first at {np.argwhere(diff)[:8].tolist()}')
