@@ -500,7 +500,8 @@ def main():
             'fp16_model_of_the_graph_max_abs_dmm_vs_fp64_oracle': round(float(np.abs(emu - exact).max()), 4),
             'f64_parity_mode_max_abs_dmm_vs_fp64_oracle': float(f'{np.abs(got64 - exact).max():.3e}'),
             'note': 'oracle = oracle/forward.py (fp64 CPU restatement; its control flow and decode are held to the reference\'s own Python executed '
-                    'in the build container (tests/golden/ref_schedule_v1.npz); the ARITHMETIC of TensorFlow\'s kernels stays unpinned: no TF); '
+                    'in the build container (tests/golden/ref_schedule_v1.npz), its backbone to the same lines run ON NUMBERS with NumPy op kernels '
+                    '(ref_forward_v1.npz, 1e-10); the arithmetic of TensorFlow\'s own kernels stays unpinned: no TF); '
                     'fp16 storage costs a few mm on this synthetic net in ANY implementation (oracle/f16emu.py is the '
                     'one-rounding-per-tensor model); the 1e-3 mm bar is met by the f64 parity mode'}
         psteps = 3
