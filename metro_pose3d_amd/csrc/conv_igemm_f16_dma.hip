@@ -348,6 +348,23 @@ __device__ __forceinline__ void conv_dma_body(
         }
     };
 
+    // ---- pre-activation BN parameters (scale | shift behind the ring) by LDS-DMA, BEFORE the ring's first requests: the oldest
+    // requests of their waves, so the counted wait of the first K step covers them and no __syncthreads (= vmcnt(0): every prologue
+    // stage landed, not just the first) stands between the prologue and the first MFMA.  1 KiB pieces of 512 channels; lanes past
+    // c_in repeat channel 0 (the K loop never reads those words).  (The fused-next-conv form keeps its ordinary loads + barrier.)
+    constexpr bool PRO_DMA = PROLOGUE && !FUSE2;
+    if constexpr (PRO_DMA) {
+#pragma unroll
+        for (int i = 0; i < (8 + NW - 1) / NW; ++i) {
+            const int id = wave * ((8 + NW - 1) / NW) + i;         // 0 ... 7: vector id >> 2 (scale, shift), piece id & 3
+            const int piece = id & 3;
+            if (id < 8 && piece * 512 < a.c_in) {
+                const int idx = piece * 512 + lane * 8;
+                const half_t* src = ((id >> 2) ? pro_shift : pro_scale) + (idx < a.c_in ? idx : 0);
+                dma16(src, __builtin_amdgcn_readfirstlane(smem_base + Cfg::MAIN_BYTES + (id >> 2) * 4096 + piece * 1024));
+            }
+        }
+    }
     // ---- main loop: STAGES-1 steps in flight -------------------------------------------------
     if constexpr (STAGES > 1) {
 #pragma unroll
@@ -377,7 +394,7 @@ __device__ __forceinline__ void conv_dma_body(
             *reinterpret_cast<uint4*>(p2 + Cfg::TM + c) = *reinterpret_cast<const uint4*>(f2.shift2 + c);
         }
     }
-    if (PROLOGUE) {
+    if (PROLOGUE && !PRO_DMA) {
         const int cpad = kc_steps * BK;
         for (int c = tid * 8; c < cpad; c += Cfg::NT * 8) {
             uint4 sv = make_uint4(0, 0, 0, 0), bv = make_uint4(0, 0, 0, 0);
@@ -390,7 +407,7 @@ __device__ __forceinline__ void conv_dma_body(
         }
     }
 
-    if (PROLOGUE) __syncthreads();   // pro_lds written
+    if (PROLOGUE && !PRO_DMA) __syncthreads();   // pro_lds written
     if constexpr (STAGES == 1) {
         // single slot (short-K layers: small LDS footprint -> several blocks per CU overlap instead)
         int cc0 = 0;
