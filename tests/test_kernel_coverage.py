@@ -34,6 +34,10 @@ CONFIGS = {
     'C3-rn50-s16-J19-b256': (ModelSpec(50, 16, 'many19'), 256),       # 152 head channels: the 160 x 256 head (whole K per wave)
     'C4-rn101-s8-J19-b32': (ModelSpec(101, 8, 'many19'), 32),
     'C5-rn50-s4-J17-b16': (ModelSpec(50, 4, 'h36m'), 16),
+    # not BASELINE configurations: head shapes the ring head kernel would otherwise never see in a test -- depth 4 (the generic
+    # statistics path: five-joint batches are for depth 8) and 128-pixel tiles with 144 weight rows (17 joints at stride 8)
+    'X-rn50-s16-J17-D4-b64': (ModelSpec(50, 16, 'h36m', depth=4), 64),
+    'X-rn50-s8-J17-b32': (ModelSpec(50, 8, 'h36m'), 32),
 }
 PERIOD = 4
 
@@ -80,6 +84,7 @@ def test_every_layer_names_its_kernel_without_a_gpu():
     assert ids['C4-rn101-s8-J19-b32']['logits'] == 'head_f16<160x128,k4>'
     assert ids['C2-rn50-s16-J17-b256']['logits'] == ids['C5-rn50-s4-J17-b16']['logits'] == 'head_f16<144x256,k2>'
     assert ids['C3-rn50-s16-J19-b256']['logits'] == 'head_f16<160x256>'
+    assert ids['X-rn50-s16-J17-D4-b64']['logits'] == 'head_f16<144x64,k4>' and ids['X-rn50-s8-J17-b32']['logits'] == 'head_f16<144x128,k4>'
     assert ids['C2-rn50-s16-J17-b64']['softargmax'] == 'softargmax_finalize<acc32>'
     # parity modes name their kernels too
     e64 = Engine(ModelSpec(50, 16, 'h36m'), None, 'f64', max_batch=2)
