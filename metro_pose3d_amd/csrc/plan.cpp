@@ -1142,6 +1142,7 @@ int metro_head_f16(const void* d_x, const void* d_w, const float* d_bias, const 
                     "head_f16: bad argument");
     METRO_CHECK_ARG(spec->n_joints_head >= 1 && spec->n_joints_head <= METRO_MAX_JOINTS && spec->n_joints_out >= 1 &&
                         spec->n_joints_out <= METRO_MAX_JOINTS, "head_f16: joint counts out of range");
+    METRO_CHECK_ARG((spec->depth * spec->n_joints_head) % 4 == 0, "head_f16: depth*n_joints_head must be a multiple of 4");
     const int side = spec->proc_side / spec->stride;
     const SoftArgmaxArgs a = make_softargmax_args(*spec, n);
     int st = launch_head_f16(d_x, d_w, d_bias, d_pro_scale, d_pro_shift, n, c_in, spec->depth * spec->n_joints_head,

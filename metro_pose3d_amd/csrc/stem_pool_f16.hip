@@ -797,7 +797,6 @@ int launch_stem_pool_f32in(const float* images, const void* w, const float* bias
         static PerDeviceInt cap;
         int grid_cap = 0;
         if (const int st = ensure_dyn_lds_and_grid_cap(reinterpret_cast<const void*>(stem_pool_rows_kernel), sp2::NT, sp2::LDS_BYTES, cap, "stem_pool_f16<rows>", 0, &grid_cap)) return st;
-        if (getenv("METRO_STEM_DEBUG")) fprintf(stderr, "stem rows: resident blocks on the device %d\n", grid_cap);
         hipLaunchKernelGGL(stem_pool_rows_kernel, dim3(n * (sp2::PS / sp2::PY)), dim3(sp2::NT), sp2::LDS_BYTES, stream, a);
         return launch_status("stem_pool_f16<rows>");
     }

@@ -143,6 +143,12 @@ def test_plan_rejects_bad_specs(lib):
         assert lib.metro_plan_create(C.byref(cs), 4, C.byref(plan)) == -1
         assert needle in lib.metro_last_error()
     assert lib.metro_plan_create(C.byref(good), 0, C.byref(plan)) == -1
+    # the one-launch head entry validates the head width itself (its bias comes in 16-byte pieces): no launch, no GPU needed
+    odd = ModelSpec(50, 16, 'h36m', depth=2).to_c(_lib.METRO_PREC_F16)              # 2 x 17 = 34 channels
+    p = C.c_void_p(256)
+    assert lib.metro_head_f16(p, p, C.cast(p, C.POINTER(C.c_float)), p, p, 1, 2048, C.byref(odd), p, None,
+                              C.cast(p, C.POINTER(C.c_float)), None) == -1
+    assert b'multiple of 4' in lib.metro_last_error()
     with pytest.raises(ValueError):
         ModelSpec(50, 12, 'h36m')
     with pytest.raises(ValueError):
