@@ -52,6 +52,58 @@ if ROOT not in sys.path:
 
 PEAK_F16_DENSE_TFLOPS = 2500.0    # /opt/skills/guides/MI355X_MICROARCH.md, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0
+_PEAKS = {}                       # measured_peaks() result of this process (one measurement per run)
+
+
+def measured_peaks():
+    """the peaks "must be confirmed on the box ... and the confirmed values written next to every reported
+    fraction".  tools/peak_probe.hip (a yardstick library, not part of the product): a register-resident
+    v_mfma_f32_32x32x16_f16 loop on all CUs for >= 2 ms on zeros / N(0,1) / relu(N(0,1)) x He-weight operands (TFLOP/s and the
+    shader clock held), and a read-only and a copy kernel on 1 GiB (beyond the 256 MiB Infinity Cache).  `frac` stays against
+    the nominal 2 500 TFLOP/s / 8 000 GB/s; these are what THIS chip delivers to a kernel with nothing else in it."""
+    if _PEAKS:
+        return _PEAKS
+    import ctypes as C
+    path = os.path.join(ROOT, 'tools', 'libmetro_probe.so')
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        _PEAKS.update({'error': f'{path}: {e} (built by __graft_entry__.build() / tools/build_probe.sh)'})
+        return _PEAKS
+    lib.metro_probe_mfma_f16.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.metro_probe_hbm.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.metro_probe_last_error.restype = C.c_char_p
+    torch.cuda.synchronize()
+    rec = {'source': 'tools/peak_probe.hip, measured in this run on this GPU'}
+    for kind, name in ((1, 'mfma_f16_random'), (2, 'mfma_f16_relu_x_he'), (0, 'mfma_f16_zeros')):
+        tf, mhz, ms = C.c_double(), C.c_double(), C.c_double()
+        if lib.metro_probe_mfma_f16(kind, 2.0, C.byref(tf), C.byref(mhz), C.byref(ms)) != 0:
+            rec[name] = {'error': lib.metro_probe_last_error().decode()}
+            continue
+        rec[name] = {'tflops': round(tf.value, 1), 'sclk_mhz': round(mhz.value), 'ms': round(ms.value, 2)}
+    for kind, name in ((0, 'hbm_read'), (1, 'hbm_copy')):
+        for size, tag in ((1 << 30, '_1GiB'), (64 << 20, '_64MiB')):
+            tb, us = C.c_double(), C.c_double()
+            if lib.metro_probe_hbm(kind, size, C.byref(tb), C.byref(us)) != 0:
+                rec[name + tag] = {'error': lib.metro_probe_last_error().decode()}
+                continue
+            rec[name + tag] = {'gb_per_s': round(tb.value * 1e3, 1), 'us': round(us.value, 1)}
+    rec['note'] = ('mfma_*: v_mfma_f32_32x32x16_f16 from registers only, 8 A x 8 B fragments rotating, 8 accumulators, 2 waves per SIMD '
+                   'on every CU; random = N(0,1) fp16 operands (what bench data toggles like), zeros = the same instructions '
+                   'on zero operands (the clock the power budget allows without data toggling).  hbm_*: 16-byte accesses, '
+                   'read + written bytes counted; _64MiB sits inside the 256 MiB Infinity Cache.')
+    _PEAKS.update(rec)
+    return _PEAKS
+
+
+def peak_measured_for(bound: str):
+    """The measured-ceiling sub-object of a roofline record (None-safe: a missing probe library is reported, not fatal)."""
+    pk = measured_peaks()
+    if 'error' in pk:
+        return {'error': pk['error']}
+    if bound == 'mfma':
+        return {k: pk[k] for k in ('mfma_f16_random', 'mfma_f16_relu_x_he', 'mfma_f16_zeros') if k in pk} | {'unit': 'TFLOP/s', 'source': pk['source']}
+    return {k: pk[k] for k in ('hbm_read_1GiB', 'hbm_copy_1GiB', 'hbm_read_64MiB', 'hbm_copy_64MiB') if k in pk} | {'unit': 'GB/s', 'source': pk['source']}
 
 
 def parse_args():
@@ -217,11 +269,22 @@ def roofline_of(eng, images, gpu_ms_per_step: float, reps: int, layer_report=Non
                 f.write(f'{li.name.decode()}\t{li.kind}\t{ms:.4f}\t{gf:.3f}\t{(gf / ms if ms > 0 else 0):.1f}\t'
                         f'{li.out_bytes_per_image * b / 1e6:.2f}\t{ab / 1e6:.2f}\t{(ab / 1e6 / ms if ms > 0 else 0):.0f}\n')
             f.write(f'TOTAL\t-\t{layer_ms.sum():.4f}\t{conv_flops / 1e9:.3f}\t{conv_flops / 1e9 / layer_ms.sum():.1f}\t-\t{algo_bytes / 1e6:.1f}\t-\n')
+    # the kernel families this forward dispatches at this batch (dry run of the plan's dispatch), with their time shares
+    fam_ms = {}
+    for ms, kid, c in zip(layer_ms, eng.layer_kernels(b), conv):
+        if c:
+            for one in kid.split(' & '):
+                fam = one.split('<')[0]
+                fam_ms[fam] = fam_ms.get(fam, 0.0) + ms / len(kid.split(' & '))
+    fams = ', '.join(f'{k} {100 * v / conv_ms_raw:.0f}%' for k, v in sorted(fam_ms.items(), key=lambda kv: -kv[1]))
+    pk = peak_measured_for('mfma')
+    rnd = pk.get('mfma_f16_random', {}).get('tflops') if isinstance(pk, dict) else None
     return {'bound': 'mfma',
-            'kernel': f'conv launches of the forward ({n_conv} per forward: conv_igemm_f16_dma, conv_gemm8p, conv3x3_f16_slab, '
-                      f'conv3x3_c64, conv_pw64, stem_pool_f16, head_f16)',
+            'kernel': f'conv launches of the forward ({n_conv} per forward; share of their time by kernel family: {fams})',
             'achieved': round(achieved, 2), 'peak': PEAK_F16_DENSE_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_F16_DENSE_TFLOPS, 4), 'traffic': None, 'traffic_note': None,
+            'frac': round(achieved / PEAK_F16_DENSE_TFLOPS, 4), 'peak_measured': pk,
+            'frac_of_measured_random_data_peak': round(achieved / rnd, 4) if rnd else None,
+            'traffic': None, 'traffic_note': None,
             'algorithmic_min_bytes': int(algo_bytes),
             'algorithmic_min_bytes_note': 'every tensor each conv launch touches, counted once per launch (MetroLayerInfo.algo_*): '
                                           'what this launch set moves if nothing is re-read',
@@ -364,7 +427,8 @@ def softargmax_hbm_leg(device, dist, stride, dataset, crops, steps, warmup, what
             'value': round(crops / (us * 1e-6), 1), 'unit': 'crops/s', 'us_per_call_median': round(us, 2), 'steps': steps,
             'finite': bool(torch.isfinite(out).all()),
             'roofline': {'bound': 'hbm', 'kernel': 'softargmax_partial<acc32,logits32> + softargmax_finalize<acc32> (both launches timed together)',
-                         'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None,
+                         'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+                         'peak_measured': peak_measured_for('hbm'), 'traffic': None,
                          'algorithmic_bytes_per_call': int(algo)}}
 
 
@@ -501,7 +565,7 @@ def main():
             'f64_parity_mode_max_abs_dmm_vs_fp64_oracle': float(f'{np.abs(got64 - exact).max():.3e}'),
             'note': 'oracle = oracle/forward.py (fp64 CPU restatement; its control flow and decode are held to the reference\'s own Python executed '
                     'in the build container (tests/golden/ref_schedule_v1.npz), its backbone to the same lines run ON NUMBERS with NumPy op kernels '
-                    '(ref_forward_v1.npz, 1e-10); the arithmetic of TensorFlow\'s own kernels stays unpinned: no TF); '
+                    '(ref_forward_v2.npz, 1e-10); the arithmetic of TensorFlow\'s own kernels stays unpinned: no TF); '
                     'fp16 storage costs a few mm on this synthetic net in ANY implementation (oracle/f16emu.py is the '
                     'one-rounding-per-tensor model); the 1e-3 mm bar is met by the f64 parity mode'}
         psteps = 3

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define METRO_ABI_VERSION 7
+#define METRO_ABI_VERSION 8
 
 typedef enum MetroStatus {
     METRO_OK = 0,
@@ -167,6 +167,10 @@ int  metro_plan_set_graph_max_batch(MetroPlan* plan, int32_t max_batch_for_graph
  * SYNCHRONISES the stream, the only entry point of the path that does.  *n_nonfinite_out = number of flagged images; returns
  * METRO_ERR_NONFINITE (metro_last_error() names the remedy: precision f32m / f64) when it is not zero. */
 int  metro_forward_status(const MetroPlan* plan, const void* d_workspace, int32_t n, void* stream, int32_t* n_nonfinite_out);
+/* Byte offset, inside the workspace, of the int32[max_batch] non-finite words metro_forward_status reads: a caller that chains
+ * several forwards (more crops than the plan's max_batch) can fold them on the device after each one and synchronise ONCE.  The
+ * words are those of the LAST forward on this workspace: valid until the next metro_forward on it, on the same stream only. */
+int64_t metro_plan_status_offset(const MetroPlan* plan);
 /* Same, stopping after layer `last_layer` (inclusive) so tests can read that layer's output at
  * MetroLayerInfo.out_offset in the workspace.  d_poses_out may be NULL if the finalize layer
  * is not reached. */
@@ -236,33 +240,18 @@ int  metro_conv_f16_next_proj(const MetroConvDesc* d, const void* d_in, const vo
                               const void* d_w_sc, const float* d_bias_sc, const void* d_pro_scale, const void* d_pro_shift, void* d_out,
                               const void* d_w2, const float* d_bias2, const void* d_scale2, const void* d_shift2, void* d_out2,
                               int32_t c2, void* stream);
-/* The same contract as metro_conv_f16 / metro_conv_f16_pair on the 256 x 256 x 64 GEMM kernel with the 8-phase
- * two-wave-group schedule (conv_gemm8p.hip), which metro_forward picks for the deep-K 1x1 layers with at least one
- * tile per CU (conv1, projection shortcut, shortcut+conv1 pair of blocks 3-4: reference resnet_v2.py:122-128).
+/* The same contract as metro_conv_f16 / metro_conv_f16_pair on the 256 x 256 x 64 GEMM kernel with four waves of 128 x 128
+ * (conv_gemm4w.hip: register-staged operands, one barrier per K tile), which metro_forward picks for the pre-activated deep-K
+ * 1x1 layers with at least one tile per CU (conv1, projection shortcut, shortcut+conv1 pair of blocks 3-4: reference
+ * resnet_v2.py:122-128; >= 256 tiles of 256 x 256, K >= 1024 or >= 1024 tiles).
  * 1x1, stride 1, c_in % 128 == 0, c_out % 256 == 0, n*h*w % 256 == 0.  split > 0: fused pair (rows [0,split) ->
- * d_out, rows [split, c_out) with ReLU -> d_out2, c_out - split == 256); split == 0: plain layer, d_out2 ignored. */
-int  metro_conv_f16_gemm8p(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
-                           const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
-                           int32_t split, void* d_out2, void* stream);
-/* The same contract and shapes on the FOUR-wave form of that GEMM (conv_gemm4w.hip: 128 x 128 wave tiles, register-staged
- * operands, one barrier per K tile), which metro_forward picks for EVERY pre-activated layer the 8-phase kernel is eligible for
- * (conv1, projection shortcut, shortcut+conv1 pair: >= 256 tiles of 256 x 256, K >= 1024 or >= 1024 tiles), whatever the batch;
- * bare GEMMs stay on the 8-phase kernel.  Bit-identical to
- * metro_conv_f16_gemm8p (same K order, one fp32 accumulator per output). */
+ * d_out, rows [split, c_out) with ReLU -> d_out2, (c_out - split) % 256 == 0); split == 0: plain layer, d_out2 ignored.
+ * Same K order and one fp32 accumulator per output as every other fp16 conv kernel here: bit-identical to them.
+ * (Two earlier forms of this GEMM that metro_forward never dispatches -- conv_gemm8p, conv_gemm4d -- are built into
+ * libmetro_experimental.so: metro_pose3d_amd/csrc/experimental/metro_experimental.h.) */
 int  metro_conv_f16_gemm4w(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                            const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
                            int32_t split, void* d_out2, void* stream);
-/* The same contract and shapes with four waves of 128 x 128 AND both operands by LDS-DMA through a ring of four 32-channel slots
- * (conv_gemm4d.hip: the geometry of gemm4w, the staging of gemm8p -- nothing passes through the issuing wave's registers on its
- * way into LDS; one barrier per 32 MFMAs; the pre-activation on the pixel fragments).  Bit-identical to the other two. */
-int  metro_conv_f16_gemm4d(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
-                           const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
-                           int32_t split, void* d_out2, void* stream);
-/* ... and with the block tile chosen: geometry 0 = 256 couts x 256 pixels (metro_conv_f16_gemm4d), 1 = 128 x 128 (wave tiles of
- * 64 x 64, two blocks per CU; c_out % 128 == 0, pixels % 128 == 0), 2 = 128 couts x 256 pixels.  Same K order, same bits. */
-int  metro_conv_f16_gemm4d_geo(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
-                               const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
-                               int32_t split, void* d_out2, int32_t geometry, void* stream);
 /* Stem 7x7/2 convolution (+bias) and zero-padded 3x3/2 max-pool in one launch (reference resnet_v2.py:219-224,
  * resnet_utils.py:138-185).  d_prepped = metro_prep_input_f16 output [n,side+6,side+8,4] fp16, d_w packed
  * [64][7][8][4] fp16, d_out fp16 [n,side/4,side/4,64].  side % 32 == 0. */

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('METRO_HIP_LIB') or os.path.join(HERE, 'libmetro_hip.so')   # override: timing experiments
 
 METRO_MAX_JOINTS = 64
-ABI_VERSION = 7          # include/metro_hip.h METRO_ABI_VERSION
+ABI_VERSION = 8          # include/metro_hip.h METRO_ABI_VERSION
 METRO_PREC_F16, METRO_PREC_F32, METRO_PREC_F64, METRO_PREC_F32M = 0, 1, 2, 3
 METRO_F16, METRO_F32, METRO_F64 = 0, 1, 2
 PARAM_CONV_W, PARAM_BIAS, PARAM_PRO_SCALE, PARAM_PRO_SHIFT = 0, 1, 2, 3
@@ -76,16 +76,14 @@ SIGNATURES = {
     'metro_plan_set_graph_max_batch': (C.c_int, [_P, C.c_int32]),
     'metro_forward': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P]),
     'metro_forward_status': (C.c_int, [_P, _P, C.c_int32, _P, C.POINTER(C.c_int32)]),
+    'metro_plan_status_offset': (C.c_int64, [_P]),
     'metro_forward_upto': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.c_int32]),
     'metro_forward_timed': (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_float)]),
     'metro_conv_f16': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f32m': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f64acc': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f16_pair': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
-    'metro_conv_f16_gemm8p': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
     'metro_conv_f16_gemm4w': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
-    'metro_conv_f16_gemm4d': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
-    'metro_conv_f16_gemm4d_geo': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, C.c_int32, _P]),
     'metro_conv_f16_conv1_conv2': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f16_next_proj': (C.c_int, [C.POINTER(MetroConvDesc)] + [_P] * 14 + [C.c_int32, _P]),
     'metro_conv_f16_next': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
@@ -110,7 +108,17 @@ SIGNATURES = {
     'metro_abi_version': (C.c_int32, []),
 }
 
+# libmetro_experimental.so (csrc/experimental/metro_experimental.h): kernels metro_forward never dispatches, kept for the
+# probes in tools/ and for tests/test_gpu_kernels.py::test_conv_gemm_experimental
+EXPERIMENTAL_LIB_PATH = os.path.join(HERE, 'libmetro_experimental.so')
+EXPERIMENTAL_SIGNATURES = {
+    'metro_conv_f16_gemm8p': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
+    'metro_conv_f16_gemm4d': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
+    'metro_conv_f16_gemm4d_geo': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, C.c_int32, _P]),
+}
+
 _lib = None
+_xlib = None
 
 
 class MetroError(RuntimeError):
@@ -141,6 +149,23 @@ def load() -> C.CDLL:
     if lib.metro_abi_version() != ABI_VERSION:
         raise MetroError(f'ABI version mismatch: library {lib.metro_abi_version()}, bindings {ABI_VERSION}')
     _lib = lib
+    return lib
+
+
+def load_experimental() -> C.CDLL:
+    """Loads libmetro_experimental.so (after the product library it links against)."""
+    global _xlib
+    if _xlib is not None:
+        return _xlib
+    load()
+    if not os.path.exists(EXPERIMENTAL_LIB_PATH):
+        raise MetroError(f'{EXPERIMENTAL_LIB_PATH} is missing: build it with `python -m metro_pose3d_amd.build`')
+    lib = C.CDLL(EXPERIMENTAL_LIB_PATH)
+    for name, (res, args) in EXPERIMENTAL_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _xlib = lib
     return lib
 
 

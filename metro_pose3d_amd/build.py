@@ -1,4 +1,7 @@
-"""Builds libmetro_hip.so (gfx950 only) in-tree with hipcc.  `python -m metro_pose3d_amd.build`."""
+"""Builds, in-tree with hipcc (gfx950 only):  `python -m metro_pose3d_amd.build`
+  libmetro_hip.so            the product: everything metro_forward can reach + the per-kernel test entries (include/metro_hip.h)
+  libmetro_experimental.so   kernels metro_forward never dispatches (csrc/experimental/, loaded by tools/ probes and one test)
+  tools/libmetro_probe.so    measured-ceiling probes for bench.py (tools/peak_probe.hip: MFMA-only loop, HBM read / copy)"""
 from __future__ import annotations
 
 import os
@@ -10,7 +13,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(HERE, 'libmetro_hip.so')
-SOURCES = ['conv_igemm_f16_dma.hip', 'conv_gemm8p.hip', 'conv_gemm4w.hip', 'conv_gemm4d.hip', 'conv3x3_f16_slab.hip', 'conv3x3_c64.hip', 'conv_pw64.hip', 'head_f16.hip', 'stem_pool_f16.hip', 'conv_igemm_f64acc.hip', 'conv_igemm_f32.hip', 'pool_softargmax.hip', 'eval_metrics.hip', 'heads.hip', 'plan.cpp']
+SOURCES = ['conv_igemm_f16_dma.hip', 'conv_gemm4w.hip', 'conv3x3_f16_slab.hip', 'conv3x3_c64.hip', 'conv_pw64.hip', 'head_f16.hip', 'stem_pool_f16.hip', 'conv_igemm_f64acc.hip', 'conv_igemm_f32.hip', 'pool_softargmax.hip', 'eval_metrics.hip', 'heads.hip', 'plan.cpp']
+EXPERIMENTAL_LIB_PATH = os.path.join(HERE, 'libmetro_experimental.so')
+EXPERIMENTAL_SOURCES = [os.path.join('experimental', f) for f in ('conv_gemm8p.hip', 'conv_gemm4d.hip', 'exp_abi.cpp')]
+EXPERIMENTAL_HEADERS = [os.path.join('experimental', 'metro_experimental.h')]
+PROBE_SRC = os.path.normpath(os.path.join(HERE, '..', 'tools', 'peak_probe.hip'))
+PROBE_LIB_PATH = os.path.normpath(os.path.join(HERE, '..', 'tools', 'libmetro_probe.so'))
 HEADERS = ['metro_common.h', os.path.join('..', '..', 'include', 'metro_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-Wall',
          '-Wno-unused-function'] + os.environ.get('METRO_EXTRA_HIPCC_FLAGS', '').split()
@@ -35,14 +43,21 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    xhdrs = hdrs + [os.path.join(CSRC, h) for h in EXPERIMENTAL_HEADERS]
     jobs = []
-    objs = []
-    for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
-        objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+
+    def objects(sources, deps):
+        objs = []
+        for src in sources:
+            s = os.path.join(CSRC, src)
+            o = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '.o')
+            objs.append(o)
+            if force or _stale(o, [s] + deps):
+                jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+        return objs
+
+    objs = objects(SOURCES, hdrs)
+    xobjs = objects(EXPERIMENTAL_SOURCES, xhdrs)
 
     def run(cmd):
         if verbose:
@@ -55,8 +70,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB_PATH, objs):
+    if force or _stale(LIB_PATH, objs):
         run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs)
+    if force or _stale(EXPERIMENTAL_LIB_PATH, xobjs + [LIB_PATH]):
+        # resolves set_error / note_kernel / validate_conv_desc / conv_gemm4w_shape_ok from the product library next to it
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', EXPERIMENTAL_LIB_PATH] + xobjs +
+            ['-L' + HERE, '-l:libmetro_hip.so', '-Wl,-rpath,$ORIGIN'])
+    if force or _stale(PROBE_LIB_PATH, [PROBE_SRC]):
+        run([hipcc, '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', PROBE_SRC, '-o', PROBE_LIB_PATH])
     return LIB_PATH
 
 

@@ -1,6 +1,6 @@
 // 1x1 convolution as a 256 x 256 x 64 GEMM with FOUR waves of 128 x 128 (gfx950) -- the deep-K 1x1 layers at large batch.
 //
-// conv_gemm8p.hip gives each of its eight waves a 128 x 64 tile: 24 ds_read_b128 per 32 MFMAs, and at batch 256 hipBLASLt's
+// experimental/conv_gemm8p.hip (round 2, no longer dispatched) gives each of its eight waves a 128 x 64 tile: 24 ds_read_b128 per 32 MFMAs, and at batch 256 hipBLASLt's
 // 256^2 kernel (four waves, 128 x 128 wave tiles: 32 reads per 64 MFMAs = two thirds of the LDS fragment bytes per MFMA) was
 // 22-28 % ahead on every deep-K shape ("the ROCm libraries on the same shapes").  This is that geometry:
 //   * one wave per SIMD, 256 fp32 accumulator registers (4 x 4 tiles of 32 x 32) + two fragment sets + one staged K tile:
@@ -305,8 +305,32 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     }
 }
 
-// same shapes as conv_gemm8p (whole 256 x 256 tiles, an even number of 64-channel K tiles)
-bool conv_gemm4w_shape_ok(const MetroConvDesc& d, const ConvSplit* split) { return conv_gemm8p_shape_ok(d, split); }
+// What the kernel can run: 1x1, stride 1, no padding, dense NHWC fp16 in/out, an even number of 64-channel K tiles,
+// WHOLE 256 x 256 tiles (no zero page here; at stride 16 every image is exactly one 256-pixel tile); a fused pair splits on a
+// tile boundary and its second output is a whole number of cout tiles (256 = conv1 of block3, 512 = conv1 of block4).
+bool conv_gemm4w_shape_ok(const MetroConvDesc& d, const ConvSplit* split) {
+    if (!(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_top == 0 && d.pad_left == 0 && d.in_pix_stride == d.c_in &&
+          d.h_in == d.h_out && d.w_in == d.w_out && d.in_dtype == METRO_F16 && d.out_dtype == METRO_F16))
+        return false;
+    const long m = (long)d.n * d.h_out * d.w_out;
+    if (d.c_in % 128 != 0 || d.c_in < 128 || d.c_in > 2048 || d.c_out % 256 != 0 || m % 256 != 0) return false;
+    if (split != nullptr && split->split > 0 && (split->split % 256 != 0 || split->c_out2 % 256 != 0 || d.has_residual)) return false;
+    return true;
+}
+
+// ... and when the dispatcher prefers it over the ring kernel: a pre-activated layer (every conv1 / projection shortcut / pair
+// is one) with deep K -- the 256 x 256 loop needs tiles to amortise its 128 KiB prologue and its epilogue -- and at least one
+// tile per CU.  Measured (MI355X): K = 512 with barely one tile per CU loses to the 128 x 256 ring kernel (block3's pair at
+// batch 64: 44 vs 41 us), at four tiles per CU it wins (batch 256: 125 vs 134 us).
+bool conv_gemm4w_supported(const MetroConvDesc& d, const ConvSplit* split) {
+    static const int enabled = tuning_knob("METRO_GEMM4W", 1);
+    static const int min_tiles = tuning_knob("METRO_GEMM8P_MIN_TILES", 256);
+    static const int min_k = tuning_knob("METRO_GEMM8P_MIN_K", 512);
+    if (!enabled || !d.has_prologue || !conv_gemm4w_shape_ok(d, split) || d.c_in < min_k) return false;
+    const long m = (long)d.n * d.h_out * d.w_out;
+    const long tiles = (long)(d.c_out / 256) * (m / 256);
+    return tiles >= min_tiles && (d.c_in >= 1024 || tiles >= 4 * min_tiles);
+}
 
 int launch_conv_gemm4w(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* ps,
                        const void* pb, const void* res, void* out, hipStream_t stream, const ConvSplit* split) {

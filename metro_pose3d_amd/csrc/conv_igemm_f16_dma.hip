@@ -351,7 +351,9 @@ __device__ __forceinline__ void conv_dma_body(
     // ---- pre-activation BN parameters (scale | shift behind the ring) by LDS-DMA, BEFORE the ring's first requests: the oldest
     // requests of their waves, so the counted wait of the first K step covers them and no __syncthreads (= vmcnt(0): every prologue
     // stage landed, not just the first) stands between the prologue and the first MFMA.  1 KiB pieces of 512 channels; lanes past
-    // c_in repeat channel 0 (the K loop never reads those words).  (The fused-next-conv form keeps its ordinary loads + barrier.)
+    // c_in take the zero page like the operand DMAs: the non-FASTK tail (c_in % BK != 0) DOES read scale / shift of channels
+    // c_in .. cpad, and 0 x (zero-filled operand) + 0 must stay 0 whatever channels 0-7 hold (a non-finite scale there would turn
+    // the padding into NaN).  (The fused-next-conv form keeps its ordinary loads + barrier.)
     constexpr bool PRO_DMA = PROLOGUE && !FUSE2;
     if constexpr (PRO_DMA) {
 #pragma unroll
@@ -360,7 +362,7 @@ __device__ __forceinline__ void conv_dma_body(
             const int piece = id & 3;
             if (id < 8 && piece * 512 < a.c_in) {
                 const int idx = piece * 512 + lane * 8;
-                const half_t* src = ((id >> 2) ? pro_shift : pro_scale) + (idx < a.c_in ? idx : 0);
+                const half_t* src = idx < a.c_in ? ((id >> 2) ? pro_shift : pro_scale) + idx : zero;
                 dma16(src, __builtin_amdgcn_readfirstlane(smem_base + Cfg::MAIN_BYTES + (id >> 2) * 4096 + piece * 1024));
             }
         }
@@ -714,29 +716,12 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
             (mode != 2 || fuse2->c2 == (d.c_in == 128 ? 128 : 64)))
             return launch_conv_pw64(d, in_, w_, bias, ps_, pb_, res_, out, stream, split, fuse2);
     }
-    if (!(fuse2 != nullptr && fuse2->w2 != nullptr) && conv_gemm8p_supported(d, split)) {
-        // the four-wave form (128 x 128 wave tiles, register-staged operands, the pre-activation applied once per element on the
-        // way into LDS) is 3-11 % ahead on every pre-activated layer (all of conv1 / shortcut / pair), batch 64-256; the bare GEMM
-        // is faster on the 8-phase kernel (tools/gemm8p_probe.py).  Same K order: the two give the same bits.
-        // ... and that geometry with BOTH operands by LDS-DMA in full 128-byte row pieces and a four-deep fragment pipeline
-        // (conv_gemm4d.hip, round 4: the structure of the library's own best kernel) is 2-8 % ahead of it on every pre-activated
-        // shape in isolation (tools/gemm8p_probe.py) and 0.2-0.7 % BEHIND inside the forward (tools/ab_bench.sh, same box, batch 64
-        // and 256): kept behind the knob, off.  Same bits again.
-        static const int four = env_int("METRO_GEMM4W", 1);
-        static const int four_d = env_int("METRO_GEMM4D", 0);
-        if (four_d && d.has_prologue) return launch_conv_gemm4d(d, in_, w_, bias, ps_, pb_, res_, out, stream, split);
-        if (four && d.has_prologue) return launch_conv_gemm4w(d, in_, w_, bias, ps_, pb_, res_, out, stream, split);
-        return launch_conv_gemm8p(d, in_, w_, bias, ps_, pb_, res_, out, stream, split);
-    }
-    {
-        // the LDS-DMA + four-deep-fragment kernel on SMALLER block tiles, for deep-K pre-activated layers whose grid is too small
-        // for 256 x 256 tiles (block3 / block4 conv1 at batch 64): 1 = 128 x 128, 2 = 128 couts x 256 pixels
-        static const int geo = env_int("METRO_G4D_GEO", 0);
-        static const int geo_min_k = env_int("METRO_G4D_GEO_MIN_K", 1024);
-        if (geo > 0 && !(fuse2 != nullptr && fuse2->w2 != nullptr) && d.has_prologue && d.c_in >= geo_min_k &&
-            conv_gemm4d_geo_ok(d, split, geo))
-            return launch_conv_gemm4d(d, in_, w_, bias, ps_, pb_, res_, out, stream, split, geo);
-    }
+    // deep-K pre-activated 1x1 layers with at least one 256 x 256 tile per CU: the four-wave GEMM (128 x 128 wave tiles,
+    // register-staged operands, the pre-activation applied once per element on its way into LDS).  Two other forms of this GEMM
+    // (8-phase two-wave-group LDS-DMA, round 2; four waves with both operands by LDS-DMA, round 4) give the same bits and
+    // measured the same inside the forward: they live in csrc/experimental/ (libmetro_experimental.so), not in the product.
+    if (!(fuse2 != nullptr && fuse2->w2 != nullptr) && conv_gemm4w_supported(d, split))
+        return launch_conv_gemm4w(d, in_, w_, bias, ps_, pb_, res_, out, stream, split);
     if (fuse2 != nullptr && fuse2->w2 != nullptr) {
         if (!conv_f16_fuse2_supported(d, fuse2->c2)) { set_error("conv fuse2: unsupported layer shape (c_out %d c2 %d k %dx%d c_in %d pix_stride %d stride %d pad %d,%d pro %d dt %d/%d hw %dx%d -> %dx%d)",
                                                                  d.c_out, fuse2->c2, d.kh, d.kw, d.c_in, d.in_pix_stride, d.stride, d.pad_top, d.pad_left, d.has_prologue,

@@ -26,7 +26,8 @@
 //     three kernels give the same bits.
 #include <type_traits>
 
-#include "metro_common.h"
+#include "../metro_common.h"
+#include "metro_experimental.h"
 
 namespace metro {
 

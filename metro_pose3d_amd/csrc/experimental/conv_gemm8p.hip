@@ -20,7 +20,8 @@
 //     fp16(conv + bias), fp16 shortcut add -- reference resnet_v2.py:119-138 under tfu.py:426-440).
 #include <type_traits>
 
-#include "metro_common.h"
+#include "../metro_common.h"
+#include "metro_experimental.h"
 
 namespace metro {
 
@@ -323,35 +324,9 @@ __global__ __launch_bounds__(g8::NT) void conv_gemm8p_kernel(
     }
 }
 
-// What the kernel can run: 1x1, stride 1, no padding, dense NHWC fp16 in/out, an even number of 64-channel K tiles,
-// WHOLE 256 x 256 tiles (no zero page here; at stride 16 every image is exactly one 256-pixel tile).
-bool conv_gemm8p_shape_ok(const MetroConvDesc& d, const ConvSplit* split) {
-    if (!(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_top == 0 && d.pad_left == 0 && d.in_pix_stride == d.c_in &&
-          d.h_in == d.h_out && d.w_in == d.w_out && d.in_dtype == METRO_F16 && d.out_dtype == METRO_F16))
-        return false;
-    const long m = (long)d.n * d.h_out * d.w_out;
-    if (d.c_in % 128 != 0 || d.c_in < 128 || d.c_in > 2048 || d.c_out % 256 != 0 || m % 256 != 0) return false;
-    if (split != nullptr && split->split > 0 && (split->split % 256 != 0 || split->c_out2 != 256 || d.has_residual)) return false;
-    return true;
-}
-
-// ... and when the planner prefers it: deep K (the 8-phase loop needs tiles to amortise its 128 KiB prologue and its
-// epilogue) and at least one tile per CU
-bool conv_gemm8p_supported(const MetroConvDesc& d, const ConvSplit* split) {
-    static const int enabled = tuning_knob("METRO_GEMM8P", 1);
-    static const int min_tiles = tuning_knob("METRO_GEMM8P_MIN_TILES", 256);
-    static const int min_k = tuning_knob("METRO_GEMM8P_MIN_K", 512);
-    if (!enabled || !conv_gemm8p_shape_ok(d, split) || d.c_in < min_k) return false;
-    const long m = (long)d.n * d.h_out * d.w_out;
-    const long tiles = (long)(d.c_out / 256) * (m / 256);
-    // measured (MI355X): K = 512 with barely one tile per CU loses to the 128 x 256 ring kernel (block3's pair at batch
-    // 64: 44 vs 41 us), at four tiles per CU it wins (batch 256: 125 vs 134 us)
-    return tiles >= min_tiles && (d.c_in >= 1024 || tiles >= 4 * min_tiles);
-}
-
 int launch_conv_gemm8p(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* ps,
                        const void* pb, const void* res, void* out, hipStream_t stream, const ConvSplit* split) {
-    if (!conv_gemm8p_shape_ok(d, split)) {
+    if (!conv_gemm4w_shape_ok(d, split)) {
         set_error("conv_gemm8p: needs a 1x1 stride-1 fp16 layer with c_in %% 128 == 0 (<= 2048), c_out %% 256 == 0 and pixels %% 256 == 0 "
                   "(got c_in %d, c_out %d, %d x %d x %d pixels)", d.c_in, d.c_out, d.n, d.h_out, d.w_out);
         return METRO_ERR_UNSUPPORTED;

@@ -220,22 +220,12 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in, const void* w, c
                         hipStream_t stream, const ConvSplit* split = nullptr, const ConvFuse2* fuse2 = nullptr,
                         const ConvProjSc* psc = nullptr);
 bool conv_f16_fuse2_supported(const MetroConvDesc& d, int c2);
-// 256 x 256 x 64 GEMM with the 8-phase two-wave-group schedule (conv_gemm8p.hip): deep-K 1x1 layers with >= 256 tiles
-bool conv_gemm8p_shape_ok(const MetroConvDesc& d, const ConvSplit* split);      // what the kernel can run
-bool conv_gemm8p_supported(const MetroConvDesc& d, const ConvSplit* split);     // ... and when the planner prefers it
-int launch_conv_gemm8p(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* pro_scale,
-                       const void* pro_shift, const void* residual, void* out, hipStream_t stream, const ConvSplit* split);
-// the same GEMM with four waves of 128 x 128 and register-staged operands (conv_gemm4w.hip): batch >= 128
-bool conv_gemm4w_shape_ok(const MetroConvDesc& d, const ConvSplit* split);
+// 256 x 256 x 64 GEMM, four waves of 128 x 128, register-staged operands (conv_gemm4w.hip): the pre-activated deep-K 1x1 layers
+// (conv1, projection shortcut, shortcut + conv1 pair of blocks 3-4) with at least one tile per CU
+bool conv_gemm4w_shape_ok(const MetroConvDesc& d, const ConvSplit* split);      // what the kernel can run
+bool conv_gemm4w_supported(const MetroConvDesc& d, const ConvSplit* split);     // ... and when the dispatcher prefers it
 int launch_conv_gemm4w(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* pro_scale,
                        const void* pro_shift, const void* residual, void* out, hipStream_t stream, const ConvSplit* split);
-// the same GEMM with four waves of 128 x 128 and BOTH operands by LDS-DMA through a ring of four 32-channel slots (conv_gemm4d.hip)
-bool conv_gemm4d_shape_ok(const MetroConvDesc& d, const ConvSplit* split);
-// tile geometry: 0 = 256 couts x 256 pixels, 1 = 128 x 128 (two blocks per CU), 2 = 128 couts x 256 pixels
-bool conv_gemm4d_geo_ok(const MetroConvDesc& d, const ConvSplit* split, int geo);
-int launch_conv_gemm4d(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* pro_scale,
-                       const void* pro_shift, const void* residual, void* out, hipStream_t stream, const ConvSplit* split = nullptr,
-                       int geo = 0);
 // persistent pipelined kernel for block1's 64-channel 1x1 convolutions (conv_pw64.hip); mode: 0 plain,
 // 1 projection shortcut + conv1 pair (c_out = 256 + 64 concatenated rows), 2 conv3 + the next unit's conv1
 bool conv_pw64_supported(const MetroConvDesc& d, int mode);

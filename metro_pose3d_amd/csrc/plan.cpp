@@ -904,6 +904,8 @@ int metro_forward_status(const MetroPlan* plan, const void* d_workspace, int32_t
     return METRO_OK;
 }
 
+int64_t metro_plan_status_offset(const MetroPlan* plan) { return plan ? plan->slot_offset[S_STATUS] : -1; }
+
 int metro_forward_upto(MetroPlan* plan, const float* d_images_nhwc, int32_t n, float* d_poses_out,
                        void* d_workspace, void* stream, int32_t last_layer) {
     return run_layers(plan, d_images_nhwc, n, d_poses_out, d_workspace, static_cast<hipStream_t>(stream), last_layer, nullptr);
@@ -993,21 +995,6 @@ int metro_conv_f16_next_proj(const MetroConvDesc* d, const void* d_in, const voi
     return launch_conv_f16_dma(*d, d_in, d_w, d_bias, nullptr, nullptr, nullptr, d_out, static_cast<hipStream_t>(stream), nullptr, &f2, &ps);
 }
 
-int metro_conv_f16_gemm8p(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
-                          const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
-                          int32_t split, void* d_out2, void* stream) {
-    int st = validate_conv_desc(d);
-    if (st) return st;
-    METRO_CHECK_ARG(d_in && d_w && d_bias && d_out, "conv_f16_gemm8p: NULL tensor pointer");
-    METRO_CHECK_ARG(!d->has_prologue || (d_pro_scale && d_pro_shift), "conv_f16_gemm8p: prologue tensors missing");
-    METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f16_gemm8p: residual tensor missing");
-    METRO_CHECK_ARG(split >= 0 && split < d->c_out && (split == 0 || d_out2), "conv_f16_gemm8p: bad split %d / missing second output", split);
-    ConvSplit sp;
-    sp.split = split; sp.c_out2 = d->c_out - split; sp.relu2 = 1; sp.out2 = d_out2;
-    return launch_conv_gemm8p(*d, d_in, d_w, d_bias, d_pro_scale, d_pro_shift, d_residual, d_out,
-                              static_cast<hipStream_t>(stream), split > 0 ? &sp : nullptr);
-}
-
 int metro_conv_f16_gemm4w(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
                           const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
                           int32_t split, void* d_out2, void* stream) {
@@ -1021,28 +1008,6 @@ int metro_conv_f16_gemm4w(const MetroConvDesc* d, const void* d_in, const void* 
     sp.split = split; sp.c_out2 = d->c_out - split; sp.relu2 = 1; sp.out2 = d_out2;
     return launch_conv_gemm4w(*d, d_in, d_w, d_bias, d_pro_scale, d_pro_shift, d_residual, d_out,
                               static_cast<hipStream_t>(stream), split > 0 ? &sp : nullptr);
-}
-
-int metro_conv_f16_gemm4d_geo(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
-                              const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
-                              int32_t split, void* d_out2, int32_t geometry, void* stream) {
-    int st = validate_conv_desc(d);
-    if (st) return st;
-    METRO_CHECK_ARG(d_in && d_w && d_bias && d_out, "conv_f16_gemm4d: NULL tensor pointer");
-    METRO_CHECK_ARG(!d->has_prologue || (d_pro_scale && d_pro_shift), "conv_f16_gemm4d: prologue tensors missing");
-    METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f16_gemm4d: residual tensor missing");
-    METRO_CHECK_ARG(split >= 0 && split < d->c_out && (split == 0 || d_out2), "conv_f16_gemm4d: bad split %d / missing second output", split);
-    METRO_CHECK_ARG(geometry >= 0 && geometry <= 2, "conv_f16_gemm4d: tile geometry %d (0 = 256 x 256, 1 = 128 x 128, 2 = 128 couts x 256 pixels)", geometry);
-    ConvSplit sp;
-    sp.split = split; sp.c_out2 = d->c_out - split; sp.relu2 = 1; sp.out2 = d_out2;
-    return launch_conv_gemm4d(*d, d_in, d_w, d_bias, d_pro_scale, d_pro_shift, d_residual, d_out,
-                              static_cast<hipStream_t>(stream), split > 0 ? &sp : nullptr, geometry);
-}
-
-int metro_conv_f16_gemm4d(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
-                          const void* d_pro_scale, const void* d_pro_shift, const void* d_residual, void* d_out,
-                          int32_t split, void* d_out2, void* stream) {
-    return metro_conv_f16_gemm4d_geo(d, d_in, d_w, d_bias, d_pro_scale, d_pro_shift, d_residual, d_out, split, d_out2, 0, stream);
 }
 
 int metro_stem_pool_f16(const void* d_prepped, const void* d_w, const float* d_bias, void* d_out, int32_t n,

@@ -4,7 +4,14 @@ No op of the path mixes images (BatchNorm is inference-mode, reference architect
 softmax is per (image, joint), volumetric.py:233), so a batch shards by image with replicated
 weights and NO activation exchange.  The only collective is one all-gather of the pose outputs
 ([N/G, Jout, 3] fp32, <= 15 KB per rank: latency-bound), RCCL over xGMI when the process group
-is `nccl`, gloo in the CPU tests.  Results are bit-identical to the single-GPU run.
+is `nccl`, gloo in the CPU tests.
+Bits: a shard has the bits of the single-GPU run as long as both run the same kernel instantiations.  In the `f64` parity
+mode that is always the case (one kernel configuration whatever the batch: tests/test_gpu_forward.py,
+test_f64_mode_is_shard_invariant).  In the `f16` throughput mode tile shapes follow the crops per call (thresholds: 128 crops
+at stride 16, 32 at stride 8, 8 at stride 4 -- see inference.estimate_pose), so a shard below a threshold and a full batch above
+it differ by fp16 rounding flips; below the thresholds the bits are the same.
+A failure on ONE rank (fp16 overflow on its shard, a HIP error) is made collective: the rank still joins the gather and its
+status row tells every rank to raise (all_gather_poses_with_status) -- nobody is left blocking in the collective.
 (The reference has no multi-GPU code at all; this is defined by BASELINE.json's north star.)
 """
 from __future__ import annotations
@@ -47,6 +54,28 @@ def all_gather_poses(local: torch.Tensor, n_total: int, group: Optional[dist.Pro
         b, e = shard_range(n_total, r, world)
         out[b:e] = buf[r * q: r * q + (e - b)]
     return out
+
+
+def all_gather_poses_with_status(local: torch.Tensor, n_total: int, status: int,
+                                 group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, list]:
+    """all_gather_poses with one extra row per rank that carries an integer status (0 = fine): STILL one collective.  Every rank
+    must call it, also the ones whose forward failed (their `local` may hold garbage): returns (poses [n_total, J, 3], the
+    status of every rank) so that all ranks can raise together instead of leaving the healthy ones blocked in the gather."""
+    world = dist.get_world_size(group)
+    j, c = local.shape[1], local.shape[2]
+    q = -(-n_total // world)
+    padded = torch.zeros((q + 1, j, c), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    padded[q, 0, 0] = float(status)
+    buf = torch.empty((world * (q + 1), j, c), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    buf = buf.view(world, q + 1, j, c)
+    statuses = [int(v) for v in buf[:, q, 0, 0].round().to(torch.int64).cpu().tolist()]
+    out = torch.empty((n_total, j, c), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        b, e = shard_range(n_total, r, world)
+        out[b:e] = buf[r, :e - b]
+    return out, statuses
 
 
 def sharded_forward(forward_fn: Callable[[torch.Tensor], torch.Tensor], images: torch.Tensor,

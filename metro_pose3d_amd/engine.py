@@ -191,6 +191,12 @@ class Engine:
         check(self.lib.metro_forward_status(self._plan, C.c_void_p(self._ws.data_ptr()), int(n), C.c_void_p(stream), C.byref(bad)),
               f'{self.spec.arch_name} stride {self.spec.stride} in precision {self.precision!r}')
 
+    def status_words(self, n: int) -> torch.Tensor:
+        """Device view (int32 [n]) of the non-finite words the LAST forward(n) on this engine wrote (1 = that crop reached the
+        soft-argmax with non-finite statistics).  No synchronisation: valid until the next forward, on the same stream."""
+        off = int(self.lib.metro_plan_status_offset(self._plan))
+        return self._ws[off:off + 4 * int(n)].view(torch.int32)
+
     def forward_upto(self, images: torch.Tensor, layer: int, second: bool = False) -> torch.Tensor:
         """Runs layers [0..layer] and returns that layer's output tensor [n,h,w,c] (a copy); `second` selects
         the second output of a fused launch (MetroLayerInfo.out2_offset)."""

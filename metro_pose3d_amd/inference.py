@@ -77,14 +77,16 @@ def _resolve_device(images_tensor: torch.Tensor) -> torch.device:
     return images_tensor.device if images_tensor.is_cuda else torch.device('cuda', torch.cuda.current_device())
 
 
-def _gather_shards(local: torch.Tensor, n_total: int, group) -> torch.Tensor:
-    """The one collective of the path: all-gather of the per-rank [n_r, Jout, 3] poses (dist.all_gather_poses).  RCCL moves
-    device tensors (backend `nccl`); any other backend (gloo in the tests) gets host tensors and the result goes back."""
+def _gather_shards(local: torch.Tensor, n_total: int, group, status: int = 0):
+    """The one collective of the path: all-gather of the per-rank [n_r, Jout, 3] poses with a status row per rank
+    (dist.all_gather_poses_with_status).  RCCL moves device tensors (backend `nccl`); any other backend (gloo in the tests) gets
+    host tensors and the result goes back.  Returns (poses, status of every rank)."""
     import torch.distributed as dist
-    from metro_pose3d_amd.dist import all_gather_poses
+    from metro_pose3d_amd.dist import all_gather_poses_with_status
     if dist.get_backend(group) == 'nccl' or not local.is_cuda:
-        return all_gather_poses(local, n_total, group)
-    return all_gather_poses(local.cpu(), n_total, group).to(local.device)
+        return all_gather_poses_with_status(local, n_total, status, group)
+    out, st = all_gather_poses_with_status(local.cpu(), n_total, status, group)
+    return out.to(local.device), st
 
 
 def estimate_pose(images_tensor, model_path, precision: Optional[str] = None, check_finite: Optional[bool] = None,
@@ -104,9 +106,13 @@ def estimate_pose(images_tensor, model_path, precision: Optional[str] = None, ch
     another fp32 summation order.  Differences are rounding flips of the fp16 chain (tests/test_gpu_forward.py); at stride 16
     calls below 128 crops agree bit for bit with one another whatever their size.
 
-    `check_finite` (default on; METRO_CHECK_FINITE=0 turns it off): after the forward, the finalize launch's non-finite screen
-    is read back (one stream synchronisation per call, as the reference's blocking sess.run) and NonFiniteError is raised when
-    activations overflowed -- a checkpoint whose residual stream exceeds fp16's 65 504 needs precision='f32m' (or 'f64')."""
+    `check_finite` (default on; METRO_CHECK_FINITE=0 turns it off): the finalize launch's non-finite screen is folded on the
+    device after every forward of the call and read back ONCE (one stream synchronisation per call, as the reference's blocking
+    sess.run); NonFiniteError is raised when activations overflowed -- a checkpoint whose residual stream exceeds fp16's 65 504
+    needs precision='f32m' (or 'f64').  Sharded calls fail COLLECTIVELY: the flag travels in the pose all-gather (one status
+    row per rank), so an overflow or an exception on one rank raises on every rank instead of leaving the others blocked in
+    the collective.  The screen reads the words of the immediately preceding forward on the engine's workspace and stream: one
+    caller per cached engine at a time (an Engine is not thread-safe, like the C plan it wraps)."""
     if precision is None:
         precision = os.environ.get('METRO_PRECISION', 'f16')
     if check_finite is None:
@@ -136,13 +142,41 @@ def estimate_pose(images_tensor, model_path, precision: Optional[str] = None, ch
     images = images_tensor[begin:end].to(device, non_blocking=True).contiguous()      # only this rank's shard goes to its GPU
     sk = eng.spec.skeleton
     poses = torch.empty((end - begin, sk.n_out, 3), dtype=torch.float32, device=device)
+    # Per-rank failures must not leave the other ranks blocked in the gather: a failing rank records its error, STILL joins the
+    # collective (its status row says so) and every rank raises afterwards.  Status: 0 fine, k > 0 = k crops of this rank's
+    # shard reached the soft-argmax non-finite (fp16 overflow), -1 = the forward itself raised.
+    status, err = 0, None
     with (torch.cuda.device(device) if device.type == 'cuda' else contextlib.nullcontext()):
-        for i in range(0, end - begin, eng.max_batch):
-            eng.forward(images[i:i + eng.max_batch], out=poses[i:i + eng.max_batch])
-            if check_finite:
-                eng.check_finite(min(eng.max_batch, end - begin - i))
+        try:
+            bad = None
+            for i in range(0, end - begin, eng.max_batch):
+                k = min(eng.max_batch, end - begin - i)
+                eng.forward(images[i:i + k], out=poses[i:i + k])
+                if check_finite:       # folded on the device after every chunk: ONE synchronisation per call, below
+                    cnt = eng.status_words(k).ne(0).sum()
+                    bad = cnt if bad is None else bad + cnt
+            if bad is not None:
+                status = int(bad.item())                                 # the call's one stream synchronisation
+        except Exception as e:          # noqa: BLE001 -- re-raised below, after the collective
+            status, err = -1, e
         if world > 1:
-            poses = _gather_shards(poses, n, group)
+            try:
+                poses, statuses = _gather_shards(poses, n, group, status)
+            except Exception:
+                if err is not None:
+                    raise err
+                raise
+        else:
+            statuses = [status]
+    if err is not None:
+        raise err
+    if any(st != 0 for st in statuses):
+        failed = ', '.join(f'rank {r}: ' + ('forward raised' if st < 0 else f'{st} crops') for r, st in enumerate(statuses) if st != 0)
+        if any(st < 0 for st in statuses):
+            raise _lib.MetroError(f'estimate_pose failed on another rank ({failed}); no poses returned on any rank')
+        raise _lib.NonFiniteError(
+            f'{eng.spec.arch_name} stride {eng.spec.stride} in precision {precision!r}: crops reached the soft-argmax with non-finite '
+            f'statistics ({failed})' + (' (fp16 storage overflows at 65504: run this model with precision f32m or f64)' if precision == 'f16' else ''))
     names = np.empty(sk.n_out, dtype=object)
     names[:] = sk.names_bytes()
     return poses, sk.edges_array(), names

@@ -30,7 +30,24 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/metro_hip.h but not exported'
     assert sorted(_lib.SIGNATURES) == declared, 'bindings and header disagree'
-    assert lib.metro_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.metro_abi_version() == _lib.ABI_VERSION == 8
+
+
+def test_experimental_and_probe_libraries_export_their_symbols(lib):
+    """libmetro_experimental.so (kernels metro_forward never dispatches) exports what its header declares and NOTHING of it is
+    in the product's header; tools/libmetro_probe.so (bench.py's measured ceilings) exports its three entry points."""
+    xhdr = os.path.join(ROOT, 'metro_pose3d_amd', 'csrc', 'experimental', 'metro_experimental.h')
+    text = re.sub(r'/\*.*?\*/', '', open(xhdr).read(), flags=re.S)
+    declared = sorted(set(re.findall(r'\b(metro_[a-z0-9_]+)\s*\(', text)))
+    assert declared == sorted(_lib.EXPERIMENTAL_SIGNATURES)
+    assert not set(declared) & set(_declared_functions())
+    xlib = _lib.load_experimental()
+    for name in declared:
+        assert hasattr(xlib, name)
+        assert not hasattr(lib, name), f'{name} is still exported by the product library'
+    probe = C.CDLL(os.path.join(ROOT, 'tools', 'libmetro_probe.so'))
+    for name in ('metro_probe_mfma_f16', 'metro_probe_hbm', 'metro_probe_last_error'):
+        assert hasattr(probe, name)
 
 
 def test_ctypes_struct_layout_matches_compiler(tmp_path):

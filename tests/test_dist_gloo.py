@@ -86,22 +86,29 @@ class _FakeEngine:
     """Stands in for Engine in the CPU test of estimate_pose's sharding logic (the real engine needs a GPU; the real-engine
     version of this test is tests/test_gpu_forward.py::test_estimate_pose_shards_across_ranks)."""
 
-    def __init__(self, max_batch):
+    def __init__(self, max_batch, bad_crops=0, raise_in_forward=False):
         from metro_pose3d_amd import ModelSpec
         self.spec = ModelSpec(50, 16, 'h36m')
         self.max_batch = max_batch
         self.calls = []
+        self.bad_crops = bad_crops                   # crops of every forward flagged non-finite by the stand-in screen
+        self.raise_in_forward = raise_in_forward
 
     def forward(self, images, out=None):
         self.calls.append(int(images.shape[0]))
+        if self.raise_in_forward:
+            raise RuntimeError('stand-in HIP failure on this rank')
         n = images.shape[0]
         flat = images.reshape(n, -1)
         res = torch.stack([flat[:, 1000 * j:1000 * j + 3] * (j + 1) for j in range(17)], dim=1)
         out.copy_(res)
         return out
 
-    def check_finite(self, n):
+    def status_words(self, n):
         self.calls.append(('check', n))
+        w = torch.zeros(n, dtype=torch.int32)
+        w[:min(self.bad_crops, n)] = 1
+        return w
 
 
 def _estimate_pose_worker(rank, world, port, n, q):
@@ -143,3 +150,59 @@ def test_estimate_pose_shards_by_image_and_gathers(world, n):
         assert p.exitcode == 0
     res = sorted(q.get(timeout=10) for _ in range(world))
     assert res == [(r, True, (n, 17, 3), 17, True, True) for r in range(world)]
+
+
+def _failing_rank_worker(rank, world, port, n, mode, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from metro_pose3d_amd import _lib
+        from metro_pose3d_amd import inference as INF
+        # only rank 1 misbehaves: its shard "overflows" (2 crops flagged) or its forward raises
+        eng = _FakeEngine(64, bad_crops=2 if (mode == 'overflow' and rank == 1) else 0,
+                          raise_in_forward=(mode == 'raise' and rank == 1))
+        INF._engine_for = lambda model_path, precision, device, n_call=64: eng
+        INF._resolve_device = lambda t: torch.device('cpu')
+        images = torch.rand((n, 256, 256, 3), generator=torch.Generator().manual_seed(3))
+        try:
+            INF.estimate_pose(images, 'unused.npz')
+            q.put((rank, 'returned', ''))
+        except _lib.NonFiniteError as e:
+            q.put((rank, 'nonfinite', str(e)))
+        except _lib.MetroError as e:
+            q.put((rank, 'metro', str(e)))
+        except RuntimeError as e:
+            q.put((rank, 'runtime', str(e)))
+        # the group is still usable: nobody is stuck in a half-joined collective
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        q.put((rank, 'after', float(t.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('mode', ['overflow', 'raise'])
+def test_a_failure_on_one_rank_raises_on_every_rank_instead_of_hanging(mode):
+    """rank 1's shard overflows fp16 / its forward raises.  Every rank must still join the one gather and
+    then raise -- the healthy rank may not block in all_gather_into_tensor until the watchdog fires."""
+    world, n = 2, 6
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_rank_worker, args=(r, world, port, n, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, 'a rank hung or crashed'
+    res = sorted(q.get(timeout=10) for _ in range(2 * world))
+    outcome = {r: (kind, msg) for r, kind, msg in res if kind != 'after'}
+    after = {r: v for r, kind, v in res if kind == 'after'}
+    assert after == {0: 1.0, 1: 1.0}
+    if mode == 'overflow':
+        assert outcome[0][0] == outcome[1][0] == 'nonfinite'
+        assert 'rank 1: 2 crops' in outcome[0][1] and 'f32m' in outcome[0][1]
+    else:
+        assert outcome[1] == ('runtime', 'stand-in HIP failure on this rank')       # the failing rank re-raises its own error
+        assert outcome[0][0] == 'metro' and 'rank 1: forward raised' in outcome[0][1]

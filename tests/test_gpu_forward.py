@@ -460,11 +460,13 @@ def test_two_ranks_real_engine_gather_equals_single_process(cuda, n):
         assert res[r].shape == want.shape and np.array_equal(res[r], want), f'rank {r}: gathered poses differ from the single-process run'
 
 
-def _estimate_pose_rank(rank, world, port, path, n, q):
+def _estimate_pose_rank(rank, world, port, path, n, q, precision=None):
     import os
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    if precision:
+        os.environ['METRO_PRECISION'] = precision
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from metro_pose3d_amd import inference as INF
@@ -508,6 +510,41 @@ def test_estimate_pose_shards_across_ranks(cuda, tmp_path, n):
         assert dev == 'cuda:0' and got.shape == want.shape == (n, 19, 3)
         assert np.array_equal(got, want), f'rank {r}: sharded estimate_pose differs from the single-process call'
         assert buckets == [INF.batch_bucket(max(-(-n // 2) if r == 0 else n // 2, 1))]      # planned for the SHARD, not for N
+
+
+def test_f64_mode_is_shard_invariant(cuda, tmp_path):
+    """"results must be bit-identical to the 1-GPU run".  In the f16 throughput mode that holds below the dispatch
+    thresholds only (tile shapes follow the crops per call); the PARITY mode runs one kernel configuration whatever the batch, so
+    the same 300 crops give the same bits as one call (chunks of 256 + 44), as five calls of 60, and as two ranks of 150 under
+    a process group (gloo on one GPU here; RCCL on a node)."""
+    import socket
+    import torch.multiprocessing as mp
+    from metro_pose3d_amd import inference as INF, save_model
+    n = 300
+    spec = ModelSpec(50, 16, 'h36m')
+    params, images = _setup(spec, n, gain=synth.logit_gain_for(50, 16))
+    path = str(tmp_path / 'rn50s16.npz')
+    save_model(path, spec, params)
+    x = torch.from_numpy(images)
+    one = INF.estimate_pose(x.to(cuda), path, precision='f64')[0].cpu().numpy()
+    five = np.concatenate([INF.estimate_pose(x[i:i + 60].to(cuda), path, precision='f64')[0].cpu().numpy() for i in range(0, n, 60)])
+    INF.clear_cache()
+    torch.cuda.empty_cache()
+    assert np.isfinite(one).all() and np.array_equal(one, five), 'f64 mode: 1 x (256 + 44) and 5 x 60 differ'
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_estimate_pose_rank, args=(r, 2, port, path, n, q, 'f64')) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: a for r, a, _, _ in (q.get(timeout=900) for _ in range(2))}
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert np.array_equal(res[r], one), f'f64 mode: rank {r} of a 2-rank sharded call differs from the single-GPU call'
 
 
 def test_fp16_overflow_is_reported_not_returned(cuda, tmp_path):

@@ -557,21 +557,28 @@ def test_error_reporting(lib):
     assert st == -1 and b'multiple of 8' in lib.metro_last_error()
 
 
-# ---- 8-phase 256 x 256 GEMM kernel (conv_gemm8p.hip) ---------------------------------------------------------------
+# ---- 256 x 256 x 64 GEMM kernels: conv_gemm4w.hip (product) + the two experimental forms (libmetro_experimental.so) --------
 # (name, images of 16x16, c_in, c_out, variant)
 G8_CASES = [('k128', 2, 128, 256, 'plain'), ('k256_relu', 3, 256, 512, 'relu'), ('k512_pro', 2, 512, 256, 'prologue'),
             ('k1024_pro_relu', 5, 1024, 512, 'prologue+relu'), ('k512_res', 3, 512, 768, 'residual'),
-            ('k2048_pro', 2, 2048, 256, 'prologue'), ('pair_k512', 3, 512, 1280, 'pair'), ('pair_k256', 2, 256, 512, 'pair')]
+            ('k2048_pro', 2, 2048, 256, 'prologue'), ('pair_k512', 3, 512, 1280, 'pair'), ('pair_k256', 2, 256, 512, 'pair'),
+            ('pair512_k1024', 2, 1024, 2560, 'pair512')]        # block4/unit_1: shortcut 2048 + conv1 512 (gemm4w only)
 
 
 @pytest.mark.parametrize('case', G8_CASES, ids=[c[0] for c in G8_CASES])
 @pytest.mark.parametrize('kernel', ['gemm8p', 'gemm4w', 'gemm4d', 'gemm4d_geo1', 'gemm4d_geo2'])
-def test_conv_gemm8p(lib, cuda, case, kernel):
+def test_conv_gemm_experimental(lib, cuda, case, kernel):
     """Every element against fp64 on the same fp16 operands: 2e-3 of the layer maximum (fp16 output rounding), for the
     plain / ReLU / pre-activation / shortcut epilogues and the fused shortcut+conv1 pair routing (reference
     resnet_v2.py:119-138), K from 2 to 32 tiles, several tiles per launch; repeated launches are bit-identical (the
     ring is ordered by hand-counted s_waitcnt vmcnt(4) + barriers between two wave groups a barrier apart)."""
     name, n, c_in, c_out, variant = case
+    xlib = _lib.load_experimental()
+    c2 = 512 if variant == 'pair512' else 256
+    if variant == 'pair512':
+        if kernel != 'gemm4w':
+            pytest.skip('a 512-wide second output exists in conv_gemm4w only')
+        variant = 'pair'
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     x, w, b = _mk(rng, n, 16, c_in, c_out, 1)
     x16, w16 = x.astype(np.float16), w.astype(np.float16)
@@ -581,7 +588,7 @@ def test_conv_gemm8p(lib, cuda, case, kernel):
     if variant == 'residual':
         res = rng.standard_normal((n, 16, 16, c_out)).astype(np.float16)
     relu = 'relu' in variant
-    split = c_out - 256 if variant == 'pair' else 0
+    split = c_out - c2 if variant == 'pair' else 0
     d = H.conv_desc(n, 16, c_in, 16, c_out, 1, prologue=pro is not None, relu=relu, residual=res is not None, res_h=16)
     tx = torch.from_numpy(x16).to(cuda)
     tw = torch.from_numpy(np.ascontiguousarray(w16.reshape(c_out, c_in))).to(cuda)
@@ -591,15 +598,16 @@ def test_conv_gemm8p(lib, cuda, case, kernel):
     tr = torch.from_numpy(res).to(cuda) if res is not None else None
     c1 = split if split else c_out
     out = torch.full((n, 16, 16, c1), float('nan'), dtype=torch.float16, device=cuda)
-    out2 = torch.full((n, 16, 16, 256), float('nan'), dtype=torch.float16, device=cuda) if split else None
+    out2 = torch.full((n, 16, 16, c2), float('nan'), dtype=torch.float16, device=cuda) if split else None
 
     if '_geo' in kernel:                                     # conv_gemm4d.hip on 128 x 128 / 128 x 256 block tiles
         geo = int(kernel[-1])
 
         def entry(*args):
-            return lib.metro_conv_f16_gemm4d_geo(*args[:-1], geo, args[-1])
+            return xlib.metro_conv_f16_gemm4d_geo(*args[:-1], geo, args[-1])
     else:
-        entry = getattr(lib, f'metro_conv_f16_{kernel}')     # conv_gemm4w.hip: four waves of 128 x 128, register-staged operands
+        # conv_gemm4w.hip (the product's kernel: four waves of 128 x 128, register-staged operands) or an experimental form
+        entry = getattr(lib if kernel == 'gemm4w' else xlib, f'metro_conv_f16_{kernel}')
 
     def run():
         check(entry(C.byref(d), H.ptr(tx), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr),
@@ -632,15 +640,15 @@ def test_conv_gemm8p(lib, cuda, case, kernel):
             junk.fill_(it)
         h1, h2 = run()
         assert torch.equal(h1, g1) and (not split or torch.equal(h2, g2)), f'{name}: launch {it} differs'
-    if kernel != 'gemm8p':                            # same K order, one fp32 accumulator per output: the two kernels give the same bits
-        check(lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(tx), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr),
+    if kernel != 'gemm8p' and c2 == 256:              # same K order, one fp32 accumulator per output: the kernels give the same bits
+        check(xlib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(tx), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr),
                                         H.ptr(out), split, H.ptr(out2), C.c_void_p(0)), 'metro_conv_f16_gemm8p')
         torch.cuda.synchronize()
         assert torch.equal(out, g1) and (not split or torch.equal(out2, g2)), f'{name}: {kernel} and gemm8p differ'
 
 
-def test_conv_gemm8p_rejects_partial_tiles(lib, cuda):
+def test_conv_gemm4w_rejects_partial_tiles(lib, cuda):
     d = H.conv_desc(1, 8, 512, 8, 256, 1)             # 64 pixels: not a whole 256-pixel tile
     t = torch.zeros(1 << 20, dtype=torch.float16, device=cuda)
-    st = lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(t), H.ptr(t), H.ptr(t.float()), None, None, None, H.ptr(t), 0, None, C.c_void_p(0))
+    st = lib.metro_conv_f16_gemm4w(C.byref(d), H.ptr(t), H.ptr(t), H.ptr(t.float()), None, None, None, H.ptr(t), 0, None, C.c_void_p(0))
     assert st == -2 and b'pixels' in lib.metro_last_error()

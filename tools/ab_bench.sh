@@ -3,7 +3,7 @@
 #   tools/ab_bench.sh <batch> <rounds> "KNOB=V ..." "KNOB=V ..." ...
 # prints ms/step per arm per round and the per-arm median.
 b=$1; rounds=$2; shift 2
-export METRO_HIP_LIB=$PWD/metro_pose3d_amd/dbg/libmetro_knobs.so
+export METRO_HIP_LIB=$PWD/metro_pose3d_amd/ab/libmetro_knobs.so
 declare -A res
 for r in $(seq 1 $rounds); do
   i=0

@@ -5,7 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, '.')
 from metro_pose3d_amd import _lib
 from tests import helpers as H
-lib = _lib.load(); dev = torch.device('cuda', 0)
+lib = _lib.load(); xlib = _lib.load_experimental(); dev = torch.device('cuda', 0)
 def run(name, n, h, c_in, c_out, pro, res, relu=False, reps=30):
     g = torch.Generator(device='cpu').manual_seed(0)
     x = torch.randn((n, h, h, c_in), generator=g).half().to(dev)
@@ -33,10 +33,10 @@ def run(name, n, h, c_in, c_out, pro, res, relu=False, reps=30):
         return res_us
     res_us = timeit(f)
     print('%-30s cold %6.1f us  warm %6.1f us  (%4.0f / %4.0f TF)  %s' % (name, res_us[0], res_us[1], gf / res_us[0] * 1e3, gf / res_us[1] * 1e3, kid))
-    if not hasattr(lib, 'metro_conv_f16_gemm4d_geo'): return
+    if not hasattr(xlib, 'metro_conv_f16_gemm4d_geo'): return
     for geo in (0, 1, 2):
         out.fill_(float('nan'))
-        g = lambda: lib.metro_conv_f16_gemm4d_geo(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc), H.ptr(sh), H.ptr(r), H.ptr(out), 0, None, geo, None)
+        g = lambda: xlib.metro_conv_f16_gemm4d_geo(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc), H.ptr(sh), H.ptr(r), H.ptr(out), 0, None, geo, None)
         if g() != 0: print('%-30s gemm4d geo %d: %s' % ('', geo, lib.metro_last_error().decode()[:60])); continue
         torch.cuda.synchronize(); same = torch.equal(out, ref)
         res_us = timeit(g)

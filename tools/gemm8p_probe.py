@@ -11,7 +11,7 @@ sys.path.insert(0, '.')
 from metro_pose3d_amd import _lib
 from tests import helpers as H
 
-lib = _lib.load()
+lib = _lib.load(); xlib = _lib.load_experimental()
 dev = torch.device('cuda', 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 SHAPES = [(2048, 512), (1024, 256), (1024, 2048), (512, 1024), (1024, 512)]
@@ -29,18 +29,18 @@ for c_in, c_out in SHAPES:
     for pro in (False, True):
         d = H.conv_desc(n, 16, c_in, 16, c_out, 1, prologue=pro)
         o8, o4 = torch.empty_like(out), torch.empty_like(out)
-        a8 = lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(o8), 0, None, C.c_void_p(0))
+        a8 = xlib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(o8), 0, None, C.c_void_p(0))
         a4 = lib.metro_conv_f16_gemm4w(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(o4), 0, None, C.c_void_p(0))
         od = torch.empty_like(out)
-        ad = lib.metro_conv_f16_gemm4d(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(od), 0, None, C.c_void_p(0))
+        ad = xlib.metro_conv_f16_gemm4d(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(od), 0, None, C.c_void_p(0))
         torch.cuda.synchronize()
         print('   bits equal to gemm8p:', a8, a4, ad, bool(torch.equal(o8, o4)), bool(torch.equal(o8, od)), float((o8.float() - od.float()).abs().max()))
         res = {}
-        for name, fn in (('gemm8p', lambda: lib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
+        for name, fn in (('gemm8p', lambda: xlib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
                                                                      H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
                          ('gemm4w', lambda: lib.metro_conv_f16_gemm4w(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
                                                                      H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
-                         ('gemm4d', lambda: lib.metro_conv_f16_gemm4d(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
+                         ('gemm4d', lambda: xlib.metro_conv_f16_gemm4d(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
                                                                      H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
                          ('hipblaslt', lambda: (torch.mm(x.view(-1, c_in), w.t(), out=out.view(-1, c_out)), 0)[1]),
                          ):

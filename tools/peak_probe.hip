@@ -1,0 +1,194 @@
+// Measured ceilings of the MI355X this process runs on ("peaks must be confirmed on the box ... a
+// STREAM-style copy kernel and an MFMA-only loop, the confirmed values written next to every reported fraction").
+//
+//   metro_probe_mfma_f16(kind, min_ms, &tflops, &sclk_mhz, &ms)
+//       register-resident v_mfma_f32_32x32x16_f16 loop, no memory traffic inside the timed region: every wave holds eight A and
+//       eight B fragments and eight independent accumulators and issues A[i] x B[j] round robin, so consecutive MFMAs see
+//       different operands (the multiplier inputs toggle as they do in a GEMM); 256 CUs x 2 waves per SIMD; runs >= min_ms.
+//       kind 0: all-zero operands; 1: N(0, 1) fp16; 2: B = relu(N(0, 1)) (a post-ReLU activation), A = N(0, 2 / 1024) (a
+//       He-initialised weight, folded BN ~ 1).  Returns TFLOP/s and the shader clock the chip held (s_memtime ticks are shader
+//       cycles, wall_clock64 is the constant 100 MHz counter: MI355X_MICROARCH.md "per-instruction cycle constants").
+//   metro_probe_hbm(kind, bytes, &tb_per_s, &us)
+//       kind 0: read-only (16-byte loads, 4 in flight per lane, grid-stride, one xor-fold per block written out);
+//       kind 1: copy (16-byte load + store).  `bytes` per pass; sizes beyond the 256 MiB Infinity Cache measure HBM, smaller
+//       ones the cache.  The rate counts read + written bytes.
+//
+// Build (tools/build_probe.sh, and __graft_entry__.build()):  hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/peak_probe.hip
+// -o tools/libmetro_probe.so.  A yardstick library for bench.py; the product (libmetro_hip.so) neither links nor loads it.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define PROBE_CHECK(x)                                                                       \
+    do {                                                                                     \
+        hipError_t e_ = (x);                                                                 \
+        if (e_ != hipSuccess) {                                                              \
+            snprintf(g_probe_err, sizeof(g_probe_err), "%s: %s", #x, hipGetErrorString(e_)); \
+            return -1;                                                                       \
+        }                                                                                    \
+    } while (0)
+
+static thread_local char g_probe_err[256] = "";
+
+// 8 waves per block (two per SIMD), one block per CU and a second one queued behind it; ITERS x 64 MFMAs per wave
+__global__ __launch_bounds__(512) void mfma_loop_kernel(const half8_t* __restrict__ frags, float* __restrict__ sink, int iters,
+                                                        unsigned long long* __restrict__ clocks) {
+    const int lane = threadIdx.x & 63;
+    half8_t a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = frags[(i * 64 + lane)];
+        b[i] = frags[((8 + i) * 64 + lane)];
+    }
+    floatx16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const unsigned long long c0 = __builtin_readcyclecounter();          // s_memtime: shader cycles
+    const unsigned long long w0 = wall_clock64();                         // constant 100 MHz
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)        // 8 independent accumulators; the operand pair changes with every MFMA
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(t + r) & 7], b[(t * 3 + r * 5) & 7], acc[t], 0, 0, 0);
+        }
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    const unsigned long long w1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[t][e];
+    if (s == 123.456f) sink[0] = s;                                       // keeps the loop alive
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = w1 - w0; }
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void hbm_read_kernel(const u32x4* __restrict__ src, size_t n16, u32x4* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32x4 f = {0, 0, 0, 0};
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 v0 = __builtin_nontemporal_load(src + i), v1 = __builtin_nontemporal_load(src + i + stride),
+                    v2 = __builtin_nontemporal_load(src + i + 2 * stride), v3 = __builtin_nontemporal_load(src + i + 3 * stride);
+        f ^= v0 ^ v1 ^ v2 ^ v3;
+    }
+    for (; i < n16; i += stride) f ^= src[i];
+    if ((f.x ^ f.y ^ f.z ^ f.w) == 0x12345678u) sink[0] = f;
+}
+
+__global__ __launch_bounds__(256) void hbm_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+        dst[i] = v0; dst[i + stride] = v1; dst[i + 2 * stride] = v2; dst[i + 3 * stride] = v3;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+// deterministic N(0, 1) (Box-Muller on an LCG): the probe must not depend on torch
+static float probe_randn(uint64_t& s) {
+    auto u = [&]() {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        return ((s >> 11) + 1) * (1.0 / 9007199254740993.0);
+    };
+    const double r = std::sqrt(-2.0 * std::log(u())), t = 6.283185307179586 * u();
+    return (float)(r * std::cos(t));
+}
+
+extern "C" {
+
+const char* metro_probe_last_error(void) { return g_probe_err; }
+
+int metro_probe_mfma_f16(int kind, double min_ms, double* tflops_out, double* sclk_mhz_out, double* ms_out) {
+    if (kind < 0 || kind > 2 || !tflops_out) { snprintf(g_probe_err, sizeof(g_probe_err), "bad argument"); return -1; }
+    const int nfrag = 16 * 64;
+    std::vector<_Float16> host((size_t)nfrag * 8);
+    uint64_t seed = 0x9e3779b97f4a7c15ull + (uint64_t)kind;
+    for (int f = 0; f < 16; ++f)
+        for (int i = 0; i < 64 * 8; ++i) {
+            float v = 0.f;
+            if (kind == 1) v = probe_randn(seed);
+            if (kind == 2) v = f < 8 ? probe_randn(seed) * std::sqrt(2.f / 1024.f) : std::fmax(probe_randn(seed), 0.f);
+            host[(size_t)f * 512 + i] = (_Float16)v;
+        }
+    half8_t* d_frags = nullptr; float* d_sink = nullptr; unsigned long long* d_clk = nullptr;
+    PROBE_CHECK(hipMalloc(&d_frags, host.size() * 2));
+    PROBE_CHECK(hipMalloc(&d_sink, 64));
+    PROBE_CHECK(hipMalloc(&d_clk, 16));
+    PROBE_CHECK(hipMemcpy(d_frags, host.data(), host.size() * 2, hipMemcpyHostToDevice));
+    int cus = 0, dev = 0;
+    PROBE_CHECK(hipGetDevice(&dev));
+    PROBE_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    hipEvent_t e0, e1;
+    PROBE_CHECK(hipEventCreate(&e0)); PROBE_CHECK(hipEventCreate(&e1));
+    const int grid = cus;                                     // one 8-wave block per CU: two waves per SIMD
+    int iters = 2000;
+    float ms = 0.f;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        hipLaunchKernelGGL(mfma_loop_kernel, dim3(grid), dim3(512), 0, 0, d_frags, d_sink, iters / 4, d_clk);   // warm-up
+        PROBE_CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(mfma_loop_kernel, dim3(grid), dim3(512), 0, 0, d_frags, d_sink, iters, d_clk);
+        PROBE_CHECK(hipEventRecord(e1, 0));
+        PROBE_CHECK(hipEventSynchronize(e1));
+        PROBE_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms >= min_ms) break;
+        iters = (int)(iters * std::fmax(1.5, 1.2 * min_ms / std::fmax(ms, 1e-3)));
+    }
+    unsigned long long clk[2] = {0, 0};
+    PROBE_CHECK(hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost));
+    const double flops = (double)grid * 8 /* waves */ * (double)iters * 64 /* MFMAs */ * 32768.0;
+    *tflops_out = flops / (ms * 1e-3) * 1e-12;
+    if (sclk_mhz_out) *sclk_mhz_out = clk[1] ? (double)clk[0] / (double)clk[1] * 100.0 : 0.0;
+    if (ms_out) *ms_out = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(d_frags); (void)hipFree(d_sink); (void)hipFree(d_clk);
+    return 0;
+}
+
+int metro_probe_hbm(int kind, int64_t bytes, double* tb_per_s_out, double* us_out) {
+    if (kind < 0 || kind > 1 || bytes < (1 << 20) || !tb_per_s_out) { snprintf(g_probe_err, sizeof(g_probe_err), "bad argument"); return -1; }
+    const size_t n16 = (size_t)bytes / 16;
+    u32x4 *src = nullptr, *dst = nullptr;
+    PROBE_CHECK(hipMalloc(&src, n16 * 16));
+    PROBE_CHECK(hipMalloc(&dst, kind == 1 ? n16 * 16 : 4096));
+    PROBE_CHECK(hipMemset(src, 0x5a, n16 * 16));
+    int cus = 0, dev = 0;
+    PROBE_CHECK(hipGetDevice(&dev));
+    PROBE_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int grid = cus * 8;
+    hipEvent_t e0, e1;
+    PROBE_CHECK(hipEventCreate(&e0)); PROBE_CHECK(hipEventCreate(&e1));
+    const int reps = 10;
+    float best = 1e30f;
+    for (int r = 0; r < reps + 2; ++r) {
+        PROBE_CHECK(hipEventRecord(e0, 0));
+        if (kind == 0) hipLaunchKernelGGL(hbm_read_kernel, dim3(grid), dim3(256), 0, 0, src, n16, dst);
+        else hipLaunchKernelGGL(hbm_copy_kernel, dim3(grid), dim3(256), 0, 0, src, dst, n16);
+        PROBE_CHECK(hipEventRecord(e1, 0));
+        PROBE_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        PROBE_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 2 && ms < best) best = ms;
+    }
+    const double moved = (double)n16 * 16 * (kind == 1 ? 2 : 1);
+    *tb_per_s_out = moved / (best * 1e-3) * 1e-12;
+    if (us_out) *us_out = best * 1e3;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(src); (void)hipFree(dst);
+    return 0;
+}
+
+}  // extern "C"
