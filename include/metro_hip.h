@@ -98,6 +98,17 @@ typedef struct MetroParamInfo {
                                            * the layer's input tensor is the unit's RAW input (c_in = its channels)          */
 #define METRO_FUSED_PROJECTION_SHORTCUT 2 /* conv3 launch that computes the unit's projection shortcut (resnet_v2.py:122-125)
                                            * from the unit's raw input instead of reading a shortcut tensor: has_residual = 0 */
+/* block1 without its 256-channel residual stream in HBM (round 5; reference resnet_v2.py:119-138 of block1's units): */
+#define METRO_FUSED_OUT_ON_CHIP 4         /* the launch's primary output (the unit's sum) is NOT written by metro_forward -- it only
+                                           * feeds the next unit's conv1 inside the launch; metro_forward_upto(last_layer = this
+                                           * layer) runs the storing form of the same kernel and writes it at out_offset        */
+#define METRO_FUSED_REBUILT_SHORTCUT 8    /* conv3 launch whose identity shortcut x_{u-1} is rebuilt in the launch from the
+                                           * 64-channel tensors it is a function of (the previous unit's conv2 output and conv3
+                                           * weights + the block's projection shortcut of the pooled stem output) instead of being
+                                           * read: has_residual / res_stride / res_offset still state the reference's shortcut   */
+#define METRO_FUSED_COMPACT_SHORTCUT 16   /* conv3 of a strided unit whose sub-sampled shortcut (resnet_v2.py:113-121) is read from
+                                           * the compact [n, h_out, w_out, c] copy the previous launch wrote at its out_sub_offset;
+                                           * has_residual / res_stride / res_offset still state the reference's gather            */
 
 typedef struct MetroLayerInfo {
     char    name[96];
@@ -120,6 +131,10 @@ typedef struct MetroLayerInfo {
      * shortcut), and the parameter tensors it reads (once per launch, batch independent). */
     int64_t algo_act_bytes_per_image;
     int64_t algo_param_bytes;
+    int64_t out_sub_offset; /* >= 0: the launch also (or only: METRO_FUSED_OUT_ON_CHIP) writes pixels (out_sub_off + 2 i,
+                             * out_sub_off + 2 j) of its primary output as a compact [n, out_sub_side, out_sub_side, c_out]
+                             * tensor here -- what the next, strided unit's shortcut reads; -1 = none                       */
+    int32_t out_sub_side, out_sub_off;
 } MetroLayerInfo;
 
 /* ---- plan life cycle: replaces tf.import_graph_def of the frozen graph
@@ -233,13 +248,32 @@ int  metro_conv_f16_next(const MetroConvDesc* d, const void* d_in, const void* d
  * metro_conv_f16_next_proj -- metro_conv_f16_next with the unit's PROJECTION shortcut computed in the launch:
  *   d_out = fp16(conv3(d_in) + bias) + fp16(Wsc * relu(d_x * pro_scale + pro_shift) + bias_sc)   (resnet_v2.py:119,122-125,134-138)
  *   d_out2 = relu(W2 * relu(d_out * scale2 + shift2) + bias2)                                    (unit u+1, :119,127-128)
- *   d->has_residual = 0; d_x fp16 [.., 64] the unit's raw input, d_w_sc fp16 [256][64], d_bias_sc fp32 [256]. */
+ *   d->has_residual = 0; d_x fp16 [.., 64] the unit's raw input, d_w_sc fp16 [256][64], d_bias_sc fp32 [256].
+ *   d_out == NULL: the sum is NOT stored (it only feeds the second GEMM): the form metro_forward runs for block1/unit_1 (round 5).
+ * metro_conv_f16_next_rebuild -- the launch of block1/unit_2 (round 5): the unit's identity shortcut x_1 is REBUILT from the tensors
+ *   it is a function of instead of being read as a 512-byte-per-pixel tensor:
+ *   x_1    = fp16(W3_prev * d_t2_prev + bias3_prev) + fp16(Wsc * relu(d_x * pro_scale + pro_shift) + bias_sc)      (unit 1, :119-138)
+ *   d_out  = fp16(conv3(d_in) + bias) + x_1                                                                        (unit 2, :120-121,134-138)
+ *   d_out2 = relu(W2 * relu(d_out * scale2 + shift2) + bias2)                                                      (unit 3, :119,127-128)
+ *   with the MFMAs, k order and fp16 roundings of the launches that would have stored x_1: the same bits.  Exactly one of d_out
+ *   (the whole sum, fp16 [n,h,w,256]) and d_out_sub (pixels (sub_off + 2i, sub_off + 2j) of it as a compact
+ *   [n, ceil((h - sub_off) / 2), ceil((w - sub_off) / 2), 256] tensor: what a strided unit 3's shortcut reads, resnet_v2.py:113-121)
+ *   must be non-NULL.  w a power of two >= 16, h * w % 64 == 0. */
 int  metro_conv_f16_conv1_conv2(const MetroConvDesc* d, const void* d_x, const void* d_w1, const float* d_bias1, const void* d_pro_scale,
                                 const void* d_pro_shift, const void* d_w2, const float* d_bias2, void* d_out, void* stream);
 int  metro_conv_f16_next_proj(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias, const void* d_x,
                               const void* d_w_sc, const float* d_bias_sc, const void* d_pro_scale, const void* d_pro_shift, void* d_out,
                               const void* d_w2, const float* d_bias2, const void* d_scale2, const void* d_shift2, void* d_out2,
                               int32_t c2, void* stream);
+int  metro_conv_f16_next_rebuild(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias, const void* d_x,
+                                 const void* d_w_sc, const float* d_bias_sc, const void* d_pro_scale, const void* d_pro_shift,
+                                 const void* d_t2_prev, const void* d_w3_prev, const float* d_bias3_prev, void* d_out, void* d_out_sub,
+                                 int32_t sub_off, const void* d_w2, const float* d_bias2, const void* d_scale2, const void* d_shift2,
+                                 void* d_out2, int32_t c2, void* stream);
+/* Test switch (thread-local) for the two entry points above when their sum stays on chip or is rebuilt: metro_forward runs them on
+ * the producer / consumer kernel of conv_b1.hip ("conv_b1_chain<...>"); 1 = run the classic single-role kernel of conv_pw64.hip
+ * instead (what metro_forward_upto stopping at such a layer runs): two independent forms that must give the same bits. */
+int  metro_conv_b1_form(int32_t classic);
 /* The same contract as metro_conv_f16 / metro_conv_f16_pair on the 256 x 256 x 64 GEMM kernel with four waves of 128 x 128
  * (conv_gemm4w.hip: register-staged operands, one barrier per K tile), which metro_forward picks for the pre-activated deep-K
  * 1x1 layers with at least one tile per CU (conv1, projection shortcut, shortcut+conv1 pair of blocks 3-4: reference

@@ -14,6 +14,7 @@ METRO_F16, METRO_F32, METRO_F64 = 0, 1, 2
 PARAM_CONV_W, PARAM_BIAS, PARAM_PRO_SCALE, PARAM_PRO_SHIFT = 0, 1, 2, 3
 LAYER_PREP, LAYER_CONV, LAYER_POOL, LAYER_SOFTARGMAX = 0, 1, 2, 3
 FUSED_CONV1_IN_FRONT, FUSED_PROJECTION_SHORTCUT = 1, 2      # MetroLayerInfo.fused_flags (METRO_FUSED_*)
+FUSED_OUT_ON_CHIP, FUSED_REBUILT_SHORTCUT, FUSED_COMPACT_SHORTCUT = 4, 8, 16
 
 
 class MetroSpec(C.Structure):
@@ -42,7 +43,8 @@ class MetroLayerInfo(C.Structure):
                 ('out_offset', C.c_int64), ('out_bytes_per_image', C.c_int64),
                 ('flops_per_image', C.c_double),
                 ('out2_offset', C.c_int64), ('out2_channels', C.c_int32), ('fused_flags', C.c_int32),
-                ('algo_act_bytes_per_image', C.c_int64), ('algo_param_bytes', C.c_int64)]
+                ('algo_act_bytes_per_image', C.c_int64), ('algo_param_bytes', C.c_int64),
+                ('out_sub_offset', C.c_int64), ('out_sub_side', C.c_int32), ('out_sub_off', C.c_int32)]
 
 
 class MetroConvDesc(C.Structure):
@@ -83,9 +85,11 @@ SIGNATURES = {
     'metro_conv_f32m': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f64acc': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f16_pair': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
+    'metro_conv_b1_form': (C.c_int, [C.c_int32]),
     'metro_conv_f16_gemm4w': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P]),
     'metro_conv_f16_conv1_conv2': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'metro_conv_f16_next_proj': (C.c_int, [C.POINTER(MetroConvDesc)] + [_P] * 14 + [C.c_int32, _P]),
+    'metro_conv_f16_next_rebuild': (C.c_int, [C.POINTER(MetroConvDesc)] + [_P] * 13 + [C.c_int32] + [_P] * 5 + [C.c_int32, _P]),
     'metro_conv_f16_next': (C.c_int, [C.POINTER(MetroConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     'metro_stem_pool_f16': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     'metro_stem_pool_f32in': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),

@@ -701,12 +701,13 @@ bool conv_f16_dma_supported(const MetroConvDesc& d) {
 
 int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_, const float* bias,
                         const void* ps_, const void* pb_, const void* res_, void* out, hipStream_t stream,
-                        const ConvSplit* split, const ConvFuse2* fuse2, const ConvProjSc* psc) {
+                        const ConvSplit* split, const ConvFuse2* fuse2, const ConvProjSc* psc, const ConvRebuild* rebuild) {
     ConvArgs a = make_conv_args(d);
     g_out2 = nullptr;
     if (psc != nullptr && psc->x != nullptr) {        // projection shortcut computed in the launch: the persistent kernel only
-        if (fuse2 != nullptr && fuse2->w2 != nullptr && fuse2->c2 == 64 && conv_pw64_supported(d, 3))
-            return launch_conv_pw64(d, in_, w_, bias, nullptr, nullptr, nullptr, out, stream, nullptr, fuse2, psc);
+        const bool rb = rebuild != nullptr && rebuild->t2_prev != nullptr;
+        if (fuse2 != nullptr && fuse2->w2 != nullptr && fuse2->c2 == 64 && conv_pw64_supported(d, rb ? 4 : 3))
+            return launch_conv_pw64(d, in_, w_, bias, nullptr, nullptr, nullptr, out, stream, nullptr, fuse2, psc, rebuild);
         set_error("conv3 with an in-launch projection shortcut: built for 1x1 stride-1 64 -> 256 + next conv1 (block1/unit_1) only");
         return METRO_ERR_UNSUPPORTED;
     }

@@ -22,6 +22,15 @@
 //                  sc = fp16(Wsc . fp16(relu(x * scale + shift)) + bias_sc) (resnet_v2.py:119,122-125) added to
 //                  fp16(conv3 + bias) in registers -- 128 instead of 512 shortcut bytes per pixel, and the launch that
 //                  wrote the shortcut tensor (512 more) is gone.
+//       OUTM / REB (round 5, block1): the 256-channel residual stream of block1's stride-1 units is never materialised.
+//                  x_1 = fp16(Wsc . pre(x0) + bsc) + fp16(W3_1 . t2_1 + b3_1) and x_2 = x_1 + fp16(W3_2 . t2_2 + b3_2) are
+//                  functions of three 64-channel tensors (128 B per pixel each, against 512 B for a stored x): the launch of unit 1
+//                  (PSC) keeps x_1 on chip -- it only feeds the next unit's conv1 (OUTM = 1: no store of `out`) -- and the
+//                  launch of unit 2 REBUILDS it (REB: a third 8 KB input tile t2_1 and W3_1 in registers next to Wsc and W3_2;
+//                  the same MFMAs in the same k order and the same fp16 roundings as the launch that would have stored it: the
+//                  same bits), adds its own conv3 and again keeps the sum on chip.  Where the next unit is strided (its
+//                  shortcut reads every second pixel, reference resnet_v2.py:113-121) the launch writes exactly those pixels as a
+//                  compact [n, h/2, w/2, 256] tensor (OUTM = 2).  block1 at batch 256: 3.29 -> 2.08 GB per forward.
 //       CB = 512   (K = 128, block2) ALL 512 output channels of a 32-pixel tile in one block (wave tile 64 couts x 32 pixels,
 //                  W3 = 64 VGPRs per lane) so that MODE2 = 2 works there too: the next unit's conv1 (512 -> 128) needs every
 //                  channel of a pixel.  Its weights W1' [128][512] live in REGISTERS as well -- wave w owns output rows
@@ -60,6 +69,11 @@ struct Pw64Args {
     const half_t* x_sc;        // PSC: [m_total][64] raw unit input; pro_scale / pro_shift are ITS pre-activation
     const half_t* w_sc;        // PSC: [256][64]
     const float* bias_sc;      // PSC: [256]
+    const half_t* in_b;        // REB: [m_total][64] conv2 output of the PREVIOUS unit
+    const half_t* w_b;         // REB: [256][64] conv3 weights of the previous unit
+    const float* bias_b;       // REB: [256]
+    half_t* out_sub;           // OUTM = 2: compact [n][h_sub][w_sub][256]: pixels (sub_off + 2 i, sub_off + 2 j) of `out`
+    int sub_off, h_sub, w_sub, lw_out;   // lw_out = log2(w_out) (the sub-sampled store needs a power of two)
     int m_total, n_tiles;
     int c_out;                 // CB * (number of CB-channel slabs); block b serves slab b % halves
     // sub-sampled shortcut (units with stride 2, reference resnet_v2.py:113-118: max_pool2d 1x1 stride 2 of the
@@ -88,9 +102,9 @@ struct Lay {
     static constexpr int OUT_BYTES = TN * OUT_ROW;
     static constexpr int RES_BYTES = TN * CB * 2;
     static constexpr int C2 = CB == 512 ? 128 : 64; // channels of a second output
-    // bias[CB] f32 | bias2[128] f32 | pro scale[K] | pro shift[K] fp16 | bias_sc[256] f32 (PSC)
-    static constexpr int BIAS2_OFF = CB * 4, PRO_OFF = BIAS2_OFF + 512, BSC_OFF = PRO_OFF + 4 * K;
-    static constexpr int PAR_BYTES = BSC_OFF + 1024;
+    // bias[CB] f32 | bias2[128] f32 | pro scale[K] | pro shift[K] fp16 | bias_sc[256] f32 (PSC) | bias_b[256] f32 (REB)
+    static constexpr int BIAS2_OFF = CB * 4, PRO_OFF = BIAS2_OFF + 512, BSC_OFF = PRO_OFF + 4 * K, BB_OFF = BSC_OFF + 1024;
+    static constexpr int PAR_BYTES = BB_OFF + 1024;
     static constexpr int X_OFF = 0;                 // 2 buffers
     static constexpr int OUT_OFF = X_OFF + 2 * X_BYTES;
     static constexpr int PAR_OFF = OUT_OFF + OUT_BYTES;
@@ -98,9 +112,9 @@ struct Lay {
     static_assert(X_BYTES % (1024 * NW) == 0, "input tile must split evenly over the waves");
     static_assert(NI >= 1 && RI >= 1 && (TN * CPR) % NT == 0, "tile / thread mismatch");
 };
-template <int K, int WM, bool RES, int MODE2, bool PSC = false, int CB = 256>
+template <int K, int WM, bool RES, int MODE2, bool PSC = false, int CB = 256, bool REB = false>
 constexpr int lds_bytes() {
-    return Lay<K, WM, CB>::RES_OFF + (RES ? 2 * Lay<K, WM, CB>::RES_BYTES : PSC ? 2 * Lay<K, WM, CB>::X_BYTES : 0);
+    return Lay<K, WM, CB>::RES_OFF + (RES ? 2 * Lay<K, WM, CB>::RES_BYTES : PSC ? (REB ? 4 : 2) * Lay<K, WM, CB>::X_BYTES : 0);
 }
 }  // namespace pw
 
@@ -118,11 +132,21 @@ template <int N>
 __device__ __forceinline__ void pw_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// vmcnt(BASE + extra), extra in [0, MAXX] wave-uniform: the wait count is an immediate
+template <int BASE, int MAXX>
+__device__ __forceinline__ void pw_wait_vm_plus(int extra) {
+    if constexpr (MAXX == 0) {
+        pw_wait_vm<BASE>();
+    } else {
+        if (extra >= MAXX) pw_wait_vm<BASE + MAXX>();
+        else pw_wait_vm_plus<BASE, MAXX - 1>(extra);
+    }
+}
 __device__ __forceinline__ void pw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false, bool PSC = false, int CB = 256>
+template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false, bool PSC = false, int CB = 256, bool REB = false, int OUTM = 0>
 __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     using namespace pw;
     using L = Lay<K, WM, CB>;
@@ -130,6 +154,8 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     static_assert(CB == 256 || (CB == 512 && K == 128 && WM == 8 && RES && !PRO && !RSUB), "512-channel blocks: conv3 of block2");
     static_assert(MODE2 == 0 || (K == 64 && WM == 4) || (MODE2 == 2 && CB == 512), "second outputs: block1 shapes, or conv3 + next conv1 of block2");
     static_assert(!PSC || (MODE2 == 2 && !PRO && !RES), "in-launch projection shortcut: conv3 + next conv1 of block1/unit_1");
+    static_assert(!REB || PSC, "rebuilt residual: on top of the in-launch projection shortcut");
+    static_assert(OUTM == 0 || (MODE2 == 2 && PSC), "outputs kept on chip: the conv3 + next conv1 launches of block1");
     constexpr int KK = K / 16, WN = L::WN, NI = L::NI, TN = L::TN, XI = L::XI, RI = L::RI;
     constexpr int X_BYTES = L::X_BYTES, X_OFF = L::X_OFF, OUT_OFF = L::OUT_OFF, PAR_OFF = L::PAR_OFF, RES_OFF = L::RES_OFF,
                   RES_BYTES = L::RES_BYTES, SL_BYTES = L::SL_BYTES, OUT_ROW = L::OUT_ROW, CPR = L::CPR, C2 = L::C2;
@@ -137,6 +163,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     typedef __attribute__((address_space(3))) void lds_void_t;
     const unsigned smem_base = (unsigned)(size_t)(lds_void_t*)smem;
     constexpr int XS_OFF = RES_OFF;                          // PSC: two buffers of the unit-input tile where the shortcut rows would be
+    constexpr int XB_OFF = XS_OFF + 2 * X_BYTES;             // REB: two buffers of the previous unit's conv2 output tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -180,6 +207,14 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
             for (int kk = 0; kk < KK; ++kk)
                 wsf[i][kk] = *reinterpret_cast<const half8_t*>(a.w_sc + (size_t)((wm * NI + i) * 32 + frag_row) * K + kk * 16 + frag_half * 8);
     }
+    half8_t wbf[NI][KK];                                     // REB: the previous unit's conv3 weights
+    if constexpr (REB) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+                wbf[i][kk] = *reinterpret_cast<const half8_t*>(a.w_b + (size_t)((wm * NI + i) * 32 + frag_row) * K + kk * 16 + frag_half * 8);
+    }
     half8_t w2f[4];
     if constexpr (MODE2 == 1) {
         if (wave < 4) {
@@ -196,6 +231,8 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     if ((PRO || PSC) && tid < K) { pro_l[tid] = a.pro_scale[tid]; pro_l[K + tid] = a.pro_shift[tid]; }
     float* bias_sc_l = reinterpret_cast<float*>(smem + PAR_OFF + L::BSC_OFF);
     if (PSC && tid < 256) bias_sc_l[tid] = a.bias_sc[tid];
+    float* bias_b_l = reinterpret_cast<float*>(smem + PAR_OFF + L::BB_OFF);
+    if (REB && tid < 256) bias_b_l[tid] = a.bias_b[tid];
     // row-wise pass: this thread always owns 16-byte chunk `ch` of a row
     const int ch = tid & (CPR - 1);
     half8_t sc2 = {}, sh2 = {};
@@ -234,6 +271,10 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
                 const half_t* ss = (m0 + xrow[i] < a.m_total) ? a.x_sc + (size_t)m0 * K + xoff[i] : zero;
                 pw_dma16(ss, __builtin_amdgcn_readfirstlane(smem_base + XS_OFF + buf * X_BYTES + (i * NW + wave) * 1024));
             }
+            if constexpr (REB) {
+                const half_t* sb = (m0 + xrow[i] < a.m_total) ? a.in_b + (size_t)m0 * K + xoff[i] : zero;
+                pw_dma16(sb, __builtin_amdgcn_readfirstlane(smem_base + XB_OFF + buf * X_BYTES + (i * NW + wave) * 1024));
+            }
         }
         if constexpr (RES) {
             // shortcut rows: chunk c = it*512 + tid (row c / CPR, 16-byte column c % CPR) lands at c*16, i.e. every
@@ -259,15 +300,18 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     // stores of one tile per wave (all younger than the next tile's loads): RI row-wise (+4 second-output)
     // second-output stores per tile: MODE2 = 1 four 8-byte stores by waves 0-3; MODE2 = 2 NTW by every wave
     constexpr int S2 = MODE2 == 2 ? NTW : 4;
+    constexpr int RS = OUTM == 0 ? RI : 0;                   // row-wise stores of `out` every tile issues (OUTM = 2: 0 .. RI, per tile)
     const bool two = MODE2 == 2 || (MODE2 == 1 && wave < 4);
     bool prev_full = false;
+    int prev_sub = 0;                                        // OUTM = 2: sub-sampled row-wise stores the previous tile issued (wave-uniform)
     for (int it = 0;; ++it, t += G) {
         const int buf = it & 1;
         const int m0 = t * TN;
         // ---- the tile's loads have landed (for this wave), then for every wave -----------------
         if (it == 0 || !prev_full) pw_wait_vm<0>();
-        else if (two) pw_wait_vm<RI + S2>();
-        else pw_wait_vm<RI>();
+        else if constexpr (OUTM == 2) pw_wait_vm_plus<S2, RI>(prev_sub);
+        else if (two) pw_wait_vm<RS + S2>();
+        else pw_wait_vm<RS>();
         pw_barrier();
         if (t + G < a.n_tiles) issue_tile(t + G, buf ^ 1);
         prev_full = m0 + TN <= a.m_total;
@@ -282,6 +326,53 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         }
         const char* xl = smem + X_OFF + buf * X_BYTES;
         const int brow = wn * 32 + frag_row;
+        // REB: the residual x_prev = fp16(W3_prev . t2_prev + b3_prev) + fp16(Wsc . pre(x0) + bsc) first, down to packed fp16
+        // (16 registers), so that its two accumulator sets are dead before this unit's conv3 accumulates
+        half4_t xprev[NI][4];
+        if constexpr (REB) {
+            // one GEMM at a time (the projection shortcut, then the previous conv3): 32 live accumulator registers, not 64
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int chunk = (kk & 3) * 2 + frag_half;
+                half8_t bs = *reinterpret_cast<const half8_t*>(smem + XS_OFF + buf * X_BYTES + (kk >> 2) * SL_BYTES + brow * 128 + ((chunk ^ pw_swz(brow)) << 4));
+                const half8_t s = *reinterpret_cast<const half8_t*>(pro_l + kk * 16 + frag_half * 8);
+                const half8_t b = *reinterpret_cast<const half8_t*>(pro_l + K + kk * 16 + frag_half * 8);
+                const half8_t z = {};
+                bs = __builtin_elementwise_max(bs * s + b, z);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) accs[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsf[i][kk], bs, accs[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const floatx4 bs = *reinterpret_cast<const floatx4*>(bias_sc_l + (wm * NI + i) * 32 + 8 * q + 4 * frag_half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xprev[i][q][e] = (half_t)(accs[i][4 * q + e] + bs[e]);
+                }
+            floatx16 accb[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accb[i][e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int chunk = (kk & 3) * 2 + frag_half;
+                const half8_t bb = *reinterpret_cast<const half8_t*>(smem + XB_OFF + buf * X_BYTES + (kk >> 2) * SL_BYTES + brow * 128 + ((chunk ^ pw_swz(brow)) << 4));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wbf[i][kk], bb, accb[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const floatx4 bv = *reinterpret_cast<const floatx4*>(bias_b_l + (wm * NI + i) * 32 + 8 * q + 4 * frag_half);
+                    half4_t hb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hb[e] = (half_t)(accb[i][4 * q + e] + bv[e]);
+                    xprev[i][q] = hb + xprev[i][q];      // the fp16 Add of the previous unit (resnet_v2.py:138), as its own launch computes it
+                }
+        }
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const int chunk = (kk & 3) * 2 + frag_half;
@@ -297,7 +388,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
             if constexpr (MODE2 == 1) {
                 if (wave < 4) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[kk], bf, acc2, 0, 0, 0);
             }
-            if constexpr (PSC) {
+            if constexpr (PSC && !REB) {
                 // projection shortcut on the pre-activated unit input (same pixels, same k step)
                 half8_t bs = *reinterpret_cast<const half8_t*>(smem + XS_OFF + buf * X_BYTES + (kk >> 2) * SL_BYTES + brow * 128 + ((chunk ^ pw_swz(brow)) << 4));
                 const half8_t s = *reinterpret_cast<const half8_t*>(pro_l + kk * 16 + frag_half * 8);
@@ -336,7 +427,8 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
                 half4_t hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) hv[e] = (half_t)(acc[i][4 * q + e] + bv[e]);
-                if constexpr (PSC) {
+                if constexpr (REB) hv = hv + xprev[i][q];      // identity shortcut of this unit: the rebuilt x_prev (resnet_v2.py:120-121,138)
+                if constexpr (PSC && !REB) {
                     // fp16(shortcut conv + bias) + fp16(conv3 + bias): the fp16 Add of the reference graph (resnet_v2.py:138)
                     const floatx4 bs = *reinterpret_cast<const floatx4*>(bias_sc_l + col);
                     half4_t hs;
@@ -350,6 +442,15 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         pw_barrier();
         // ---- row-wise: 16 bytes per lane, + shortcut, full-row stores ---------------------------
         const char* rl = smem + RES_OFF + buf * RES_BYTES;
+        // OUTM = 2: which of the RI row-wise instructions of this tile hold pixels the next (strided) unit's shortcut reads.  A
+        // wave's instruction r covers pixels 16 r + 2 w, + 1 of the tile: one map row (w_out >= 16, a power of two), both column
+        // parities -- so whether it stores is a property of (tile, r), the same for every wave: the store count stays countable.
+        int img0 = 0, rem0 = 0, now_sub = 0;
+        if constexpr (OUTM == 2) {
+            const int hw = a.h_out * a.w_out;
+            img0 = m0 / hw;
+            rem0 = m0 - img0 * hw;
+        }
 #pragma unroll
         for (int r = 0; r < RI; ++r) {
             const int idx = tid + r * NT;
@@ -363,7 +464,18 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = x[e] + rr[e];       // fp16 Add, like the reference graph
             }
-            if (m < a.m_total) store_out16<1>(a.out + (size_t)m * ldo + ch * 8, v);
+            if constexpr (OUTM == 0) {
+                if (m < a.m_total) store_out16<1>(a.out + (size_t)m * ldo + ch * 8, v);
+            }
+            if constexpr (OUTM == 2) {
+                const int hr = ((rem0 + 16 * r) >> a.lw_out) - a.sub_off;         // wave-uniform: map row of this instruction's pixels
+                if (hr >= 0 && (hr & 1) == 0 && (hr >> 1) < a.h_sub) {
+                    ++now_sub;
+                    const int wo = ((rem0 + prow) & (a.w_out - 1)) - a.sub_off;
+                    if (wo >= 0 && (wo & 1) == 0 && (wo >> 1) < a.w_sub)
+                        store_out16<1>(a.out_sub + (((size_t)img0 * a.h_sub + (hr >> 1)) * a.w_sub + (wo >> 1)) * CB + ch * 8, v);
+                }
+            }
             if constexpr (MODE2 == 2) {
                 // next unit's pre-activation (fp16 BN + ReLU) goes back into the tile for the second GEMM
                 const half8_t z = {};
@@ -400,6 +512,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
                 if (m < a.m_total) *reinterpret_cast<half4_t*>(a.out2 + (size_t)m * C2 + co) = hv;
             }
         }
+        prev_sub = now_sub;
         if (t + G >= a.n_tiles) break;
     }
 }
@@ -429,6 +542,11 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
         return ((d.c_in == 64 && d.c_out == 256) || (next128 && d.c_in == 128 && d.c_out == 512 && res_plain)) && !d.has_prologue && d.has_residual;
     }
     if (mode == 3) return d.c_in == 64 && d.c_out == 256 && !d.has_prologue && !d.has_residual;    // + in-launch projection shortcut
+    if (mode == 4) {           // + the residual rebuilt from the previous unit's conv2 output (and optionally kept on chip)
+        const int hw = d.h_out * d.w_out;
+        return d.c_in == 64 && d.c_out == 256 && !d.has_prologue && !d.has_residual && hw % 64 == 0 && d.w_out >= 16 &&
+               (d.w_out & (d.w_out - 1)) == 0;
+    }
     if (d.c_in == 64 && d.c_out == 256) return (d.has_prologue != 0) != (d.has_residual != 0);
     // conv3 (+ shortcut) of blocks 2-4: c_out = 4 * c_in in 256-channel slabs (METRO_PW_MAXK caps c_in for A/B runs)
     static const int maxk = pw_env_int("METRO_PW_MAXK", 512);
@@ -436,13 +554,14 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
            !d.has_prologue && d.has_residual;
 }
 
-template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false, bool PSC = false, int CB = 256>
+template <int K, int WM, bool PRO, bool RES, int MODE2, bool RSUB = false, bool PSC = false, int CB = 256, bool REB = false, int OUTM = 0>
 static int launch_pw(Pw64Args a, hipStream_t stream) {
-    if (note_kernel("conv_pw64<k%d,wm%d%s%s%s%s%s%s>", K, WM, CB == 512 ? ",cb512" : "", PRO ? ",pro" : "", RES ? ",res" : "",
-                    MODE2 == 1 ? ",pair" : MODE2 == 2 ? ",next" : "", RSUB ? ",ressub" : "", PSC ? ",projsc" : ""))
+    if (note_kernel("conv_pw64<k%d,wm%d%s%s%s%s%s%s%s%s>", K, WM, CB == 512 ? ",cb512" : "", PRO ? ",pro" : "", RES ? ",res" : "",
+                    MODE2 == 1 ? ",pair" : MODE2 == 2 ? ",next" : "", RSUB ? ",ressub" : "", PSC ? ",projsc" : "", REB ? ",rebuild" : "",
+                    OUTM == 1 ? ",noout" : OUTM == 2 ? ",subout" : ""))
         return METRO_OK;
-    auto kern = conv_pw64_kernel<K, WM, PRO, RES, MODE2, RSUB, PSC, CB>;
-    constexpr int lds = pw::lds_bytes<K, WM, RES, MODE2, PSC, CB>();
+    auto kern = conv_pw64_kernel<K, WM, PRO, RES, MODE2, RSUB, PSC, CB, REB, OUTM>;
+    constexpr int lds = pw::lds_bytes<K, WM, RES, MODE2, PSC, CB, REB>();
     a.n_tiles = (a.m_total + pw::Lay<K, WM, CB>::TN - 1) / pw::Lay<K, WM, CB>::TN;
     static PerDeviceInt cap;
     int grid_cap = 0;
@@ -458,15 +577,26 @@ static int launch_pw(Pw64Args a, hipStream_t stream) {
 
 int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* ps,
                      const void* pb, const void* res, void* out, hipStream_t stream, const ConvSplit* split,
-                     const ConvFuse2* f2, const ConvProjSc* psc) {
+                     const ConvFuse2* f2, const ConvProjSc* psc, const ConvRebuild* rb) {
     const bool proj = psc != nullptr && psc->x != nullptr;
-    const int mode = (f2 != nullptr && f2->w2 != nullptr) ? (proj ? 3 : 2) : (split != nullptr && split->split > 0) ? 1 : 0;
-    if (proj && mode != 3) { set_error("conv_pw64: the in-launch projection shortcut exists for conv3 + next conv1 only"); return METRO_ERR_INVALID_ARG; }
+    const bool reb = rb != nullptr && rb->t2_prev != nullptr;
+    const int outm = rb != nullptr ? rb->out_mode : 0;
+    const int mode = (f2 != nullptr && f2->w2 != nullptr) ? (proj ? (reb ? 4 : 3) : 2) : (split != nullptr && split->split > 0) ? 1 : 0;
+    if (proj && mode < 3) { set_error("conv_pw64: the in-launch projection shortcut exists for conv3 + next conv1 only"); return METRO_ERR_INVALID_ARG; }
+    if ((reb || outm != 0) && mode < 3) { set_error("conv_pw64: rebuilt residual / on-chip output exist on top of the in-launch projection shortcut only"); return METRO_ERR_INVALID_ARG; }
+    if (outm < 0 || outm > 2 || (outm == 2 && !(reb && rb->out_sub != nullptr && rb->sub_off >= 0 && rb->sub_off <= 1 && rb->h_sub > 0 && rb->w_sub > 0)) ||
+        (outm == 0 && out == nullptr)) {
+        set_error("conv_pw64: bad output mode %d (2 = sub-sampled copy: needs the rebuilt residual, out_sub, sub_off 0|1 and the sub-sampled map size)", outm);
+        return METRO_ERR_INVALID_ARG;
+    }
     if (!conv_pw64_supported(d, mode) || (mode == 1 && !(split->split == 256 && split->c_out2 == 64 && split->relu2 == 1)) ||
         (mode >= 2 && f2->c2 != (d.c_in == 128 ? 128 : 64))) {
         set_error("conv_pw64: unsupported layer");
         return METRO_ERR_INVALID_ARG;
     }
+    // the launches whose sum stays on chip (or is rebuilt): the producer / consumer form, unless the classic one is asked for
+    if (mode >= 3 && rb != nullptr && !rb->classic && (reb || outm == 1) && conv_b1_chain_preferred() && conv_pw64_supported(d, 4))
+        return launch_conv_b1_chain(d, in, w, bias, out, stream, *f2, *psc, *rb);
     Pw64Args a;
     a.in = static_cast<const half_t*>(in);
     a.w = static_cast<const half_t*>(w);
@@ -477,6 +607,7 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
     a.out = static_cast<half_t*>(out);
     a.w2 = nullptr; a.bias2 = nullptr; a.scale2 = nullptr; a.shift2 = nullptr; a.out2 = nullptr;
     a.x_sc = nullptr; a.w_sc = nullptr; a.bias_sc = nullptr;
+    a.in_b = nullptr; a.w_b = nullptr; a.bias_b = nullptr; a.out_sub = nullptr; a.sub_off = 0; a.h_sub = 0; a.w_sub = 0; a.lw_out = 0;
     a.m_total = d.n * d.h_out * d.w_out;
     a.n_tiles = 0;
     a.c_out = mode == 1 ? 256 : d.c_out;
@@ -491,9 +622,21 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
         a.w2 = static_cast<const half_t*>(f2->w2); a.bias2 = f2->bias2;
         a.scale2 = static_cast<const half_t*>(f2->scale2); a.shift2 = static_cast<const half_t*>(f2->shift2);
         a.out2 = static_cast<half_t*>(f2->out2);
-        if (mode == 3) {
+        if (mode >= 3) {
             a.x_sc = static_cast<const half_t*>(psc->x); a.w_sc = static_cast<const half_t*>(psc->w_sc); a.bias_sc = psc->bias_sc;
             a.pro_scale = static_cast<const half_t*>(psc->pro_scale); a.pro_shift = static_cast<const half_t*>(psc->pro_shift);
+            if (reb) {
+                a.in_b = static_cast<const half_t*>(rb->t2_prev); a.w_b = static_cast<const half_t*>(rb->w3_prev); a.bias_b = rb->bias3_prev;
+                if (a.w_b == nullptr || a.bias_b == nullptr) { set_error("conv_pw64: rebuilt residual without the previous unit's conv3 parameters"); return METRO_ERR_INVALID_ARG; }
+                if (outm == 2) {
+                    a.out_sub = static_cast<half_t*>(rb->out_sub); a.sub_off = rb->sub_off; a.h_sub = rb->h_sub; a.w_sub = rb->w_sub;
+                    while ((1 << a.lw_out) < d.w_out) ++a.lw_out;
+                    return launch_pw<64, 4, false, false, 2, false, true, 256, true, 2>(a, stream);
+                }
+                if (outm == 1) { set_error("conv_pw64: a rebuilt residual whose sum is neither stored nor sub-sampled has no consumer"); return METRO_ERR_INVALID_ARG; }
+                return launch_pw<64, 4, false, false, 2, false, true, 256, true, 0>(a, stream);
+            }
+            if (outm == 1) return launch_pw<64, 4, false, false, 2, false, true, 256, false, 1>(a, stream);
             return launch_pw<64, 4, false, false, 2, false, true>(a, stream);
         }
         if (d.c_in == 128) return launch_pw<128, 8, false, true, 2, false, false, 512>(a, stream);

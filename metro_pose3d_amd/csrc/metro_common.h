@@ -183,6 +183,24 @@ struct ConvProjSc {
     const void* pro_shift = nullptr;
 };
 
+// block1 without its 256-channel residual stream in HBM (conv_pw64.hip REB / OUTM, round 5).  The launch conv3(u) + conv1(u+1):
+//   t2_prev != NULL  the unit's identity shortcut x_{u-1} is REBUILT in the launch from the previous unit's conv2 output and conv3
+//                    parameters + the projection shortcut of ConvProjSc (x_{u-1} = fp16(W3_prev . t2_prev + b) + fp16(Wsc . pre(x0) + bsc)),
+//                    reference resnet_v2.py:119-125,134-138 of unit u-1, instead of being read as a 512-byte-per-pixel tensor;
+//   out_mode         0 = the launch's sum is stored in full, 1 = not at all (it only feeds the next unit's conv1 in the launch),
+//                    2 = only the pixels (sub_off + 2 i, sub_off + 2 j) the next, strided unit's shortcut reads (resnet_v2.py:113-121;
+//                    resnet_utils.py:64-79), as a compact [n, h_sub, w_sub, 256] tensor.
+struct ConvRebuild {
+    const void* t2_prev = nullptr;     // fp16 [pixels][64]
+    const void* w3_prev = nullptr;     // fp16 [256][64]
+    const float* bias3_prev = nullptr; // [256]
+    int out_mode = 0;
+    void* out_sub = nullptr;
+    int sub_off = 0, h_sub = 0, w_sub = 0;
+    int classic = 0;                   // 1 = the single-role kernel of conv_pw64.hip even where conv_b1.hip's producer / consumer form
+                                       // would be dispatched (metro_forward_upto stopping at the layer: an independent second form)
+};
+
 struct ConvArgs {
     int split, c_out2, relu2;   // see ConvSplit (0 = plain convolution)
     int n, h_in, w_in, c_in, in_pix_stride;
@@ -218,7 +236,7 @@ bool conv_f16_dma_supported(const MetroConvDesc& d);
 int launch_conv_f16_dma(const MetroConvDesc& d, const void* in, const void* w, const float* bias,
                         const void* pro_scale, const void* pro_shift, const void* residual, void* out,
                         hipStream_t stream, const ConvSplit* split = nullptr, const ConvFuse2* fuse2 = nullptr,
-                        const ConvProjSc* psc = nullptr);
+                        const ConvProjSc* psc = nullptr, const ConvRebuild* rebuild = nullptr);
 bool conv_f16_fuse2_supported(const MetroConvDesc& d, int c2);
 // 256 x 256 x 64 GEMM, four waves of 128 x 128, register-staged operands (conv_gemm4w.hip): the pre-activated deep-K 1x1 layers
 // (conv1, projection shortcut, shortcut + conv1 pair of blocks 3-4) with at least one tile per CU
@@ -227,11 +245,18 @@ bool conv_gemm4w_supported(const MetroConvDesc& d, const ConvSplit* split);     
 int launch_conv_gemm4w(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* pro_scale,
                        const void* pro_shift, const void* residual, void* out, hipStream_t stream, const ConvSplit* split);
 // persistent pipelined kernel for block1's 64-channel 1x1 convolutions (conv_pw64.hip); mode: 0 plain,
-// 1 projection shortcut + conv1 pair (c_out = 256 + 64 concatenated rows), 2 conv3 + the next unit's conv1
+// 1 projection shortcut + conv1 pair (c_out = 256 + 64 concatenated rows), 2 conv3 + the next unit's conv1, 3 = 2 with the projection
+// shortcut computed in the launch, 4 = 3 with the residual rebuilt / the sum kept on chip (ConvRebuild)
 bool conv_pw64_supported(const MetroConvDesc& d, int mode);
 int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* pro_scale,
                      const void* pro_shift, const void* residual, void* out, hipStream_t stream,
-                     const ConvSplit* split, const ConvFuse2* fuse2, const ConvProjSc* psc = nullptr);
+                     const ConvSplit* split, const ConvFuse2* fuse2, const ConvProjSc* psc = nullptr,
+                     const ConvRebuild* rebuild = nullptr);
+// producer / consumer form of the conv3 + next conv1 launches of block1 whose sum stays on chip (conv_b1.hip)
+bool conv_b1_chain_preferred();
+void conv_b1_set_form(int classic);      // thread-local test switch: 1 = never dispatch it
+int launch_conv_b1_chain(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out, hipStream_t stream,
+                         const ConvFuse2& f2, const ConvProjSc& psc, const ConvRebuild& rb);
 // stem 7x7/2 conv + zero-padded 3x3/2 max-pool in one persistent kernel (stem_pool_f16.hip); input is the
 // bordered 4-channel fp16 image of launch_prep_input_f16, weights packed [64][7][8][4]
 bool stem_pool_f16_supported(int side, int base_width);

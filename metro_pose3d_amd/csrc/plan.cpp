@@ -81,7 +81,7 @@ using namespace metro;
 namespace {
 
 enum LayerKind { LK_PREP = 0, LK_CONV = 1, LK_POOL = 2, LK_SOFTARGMAX = 3 };
-enum Slot { S_IMAGES = -2, S_NONE = -1, S_PREP = 0, S_STEM, S_X0, S_X1, S_T1, S_T2, S_SC, S_LOGITS, S_PART, S_STATUS, S_COUNT };
+enum Slot { S_IMAGES = -2, S_NONE = -1, S_PREP = 0, S_STEM, S_X0, S_X1, S_T1, S_T2, S_T2B, S_SC, S_LOGITS, S_PART, S_STATUS, S_COUNT };
 
 struct Layer {
     MetroLayerInfo info;
@@ -98,6 +98,11 @@ struct Layer {
     // parameters and the slot of the unit's input)
     int p1_w, p1_bias, p1_scale, p1_shift;
     int psc_w, psc_bias, psc_scale, psc_shift, psc_slot;
+    // block1 without its 256-channel residual stream in HBM (round 5, conv_pw64 REB / OUTM): parameters and slot of the PREVIOUS
+    // unit's conv3 (the shortcut is rebuilt from them + psc_*), what metro_forward does with the launch's sum (0 store, 1 keep on
+    // chip, 2 sub-sampled compact copy into sub_slot only) and the geometry of that copy
+    int reb_w, reb_bias, reb_slot;
+    int out_mode, sub_slot, sub_off, sub_side;
     int stem_pool;        // stem conv + max-pool in one launch (the layer's output is the pooled tensor)
     int head_c_in;        // soft-argmax layer of a fused head: input channels of the logits GEMM (which head kernel ran)
     int head_fused;       // logits layer: GEMM + per-joint softmax statistics in one launch (head_f16.hip); the
@@ -177,7 +182,7 @@ struct Builder {
                   int out_dtype, int in_dtype) {
         Layer L;
         memset(&L, 0, sizeof(L));
-        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE;
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE; L.reb_w = L.reb_bias = -1; L.reb_slot = L.sub_slot = S_NONE;
         L.kind = LK_CONV;
         const bool fast = p->fast;
         const bool f32m = p->spec.precision == METRO_PREC_F32M;
@@ -220,7 +225,7 @@ struct Builder {
                                 int c_sc, int cb, int adt) {
         Layer L;
         memset(&L, 0, sizeof(L));
-        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE;
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE; L.reb_w = L.reb_bias = -1; L.reb_slot = L.sub_slot = S_NONE;
         L.kind = LK_CONV;
         MetroConvDesc& cd = L.cd;
         cd.h_in = cd.w_in = side; cd.c_in = c_in; cd.in_pix_stride = c_in;
@@ -353,7 +358,7 @@ int build_plan(MetroPlan* p) {
     if (fast) {
         Layer L;
         memset(&L, 0, sizeof(L));
-        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE;
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE; L.reb_w = L.reb_bias = -1; L.reb_slot = L.sub_slot = S_NONE;
         L.kind = LK_PREP;
         L.cd.h_in = L.cd.w_in = side; L.cd.c_in = 3;
         L.cd.h_out = side + 6; L.cd.w_out = side + 8; L.cd.c_out = 4; L.cd.out_dtype = METRO_F16;
@@ -370,7 +375,7 @@ int build_plan(MetroPlan* p) {
         // the 8th pixel and the 4th channel).
         Layer S;
         memset(&S, 0, sizeof(S));
-        S.f2_w = S.f2_bias = S.f2_scale = S.f2_shift = -1; S.p1_w = S.p1_bias = S.p1_scale = S.p1_shift = -1; S.psc_w = S.psc_bias = S.psc_scale = S.psc_shift = -1; S.psc_slot = S_NONE;
+        S.f2_w = S.f2_bias = S.f2_scale = S.f2_shift = -1; S.p1_w = S.p1_bias = S.p1_scale = S.p1_shift = -1; S.psc_w = S.psc_bias = S.psc_scale = S.psc_shift = -1; S.psc_slot = S_NONE; S.reb_w = S.reb_bias = -1; S.reb_slot = S.sub_slot = S_NONE;
         S.kind = LK_CONV;
         MetroConvDesc& cd = S.cd;
         cd.h_in = side + 6; cd.w_in = side + 8; cd.c_in = 32; cd.in_pix_stride = 4;
@@ -406,7 +411,7 @@ int build_plan(MetroPlan* p) {
     if (!fused_stem_pool) {
         Layer L;
         memset(&L, 0, sizeof(L));
-        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE;
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE; L.reb_w = L.reb_bias = -1; L.reb_slot = L.sub_slot = S_NONE;
         L.kind = LK_POOL;
         L.cd.h_in = L.cd.w_in = s2; L.cd.c_in = bw; L.cd.h_out = L.cd.w_out = s4; L.cd.c_out = bw;
         L.cd.kh = L.cd.kw = 3; L.cd.stride = 2; L.cd.dilation = 1; L.cd.pad_top = L.cd.pad_left = 1;
@@ -439,6 +444,11 @@ int build_plan(MetroPlan* p) {
     int current_stride = 1, rate = 1;
     int cur_side = s4, cur_c = bw, cur = S_X0;
     bool conv1_done = false;      // conv1 of this unit already ran inside the previous unit's conv3 launch
+    // block1 without its 256-channel residual stream in HBM (round 5): 0 = off, 1 = unit 1 planned (x_1 stays on chip), 2 = unit 2
+    // planned (x_1 rebuilt in its conv3 launch; x_2 on chip / sub-sampled / stored).  chain_l1 = layer index of unit 1's conv3
+    // launch, chain_x0 = slot of the block's input, cur_compact = `cur` holds the sub-sampled compact copy of the unit input.
+    int chain = 0, chain_l1 = -1, chain_x0 = S_NONE;
+    bool cur_compact = false;
     for (int b = 0; b < 4; ++b) {
         for (int u = 1; u <= n_units[b]; ++u) {
             const int unit_stride = u == n_units[b] ? block_stride[b] : 1;   // resnet_v2.py:260-269
@@ -485,6 +495,18 @@ int build_plan(MetroPlan* p) {
                 c3.kh = c3.kw = 1; c3.pad_top = c3.pad_left = 0; c3.relu = 0; c3.c_out = 256;
                 unit_fused = conv3x3_c64_supported(c2) && conv_pw64_supported(c3, 3);
             }
+            // ... and none of the block's 256-channel sums in HBM (conv_pw64 REB / OUTM): three units, the second one plain
+            bool chain_start = false;
+            if (unit_fused && u == 1 && n_units[b] == 3 && tuning_knob("METRO_B1_REBUILD", 1)) {
+                MetroConvDesc c3;
+                memset(&c3, 0, sizeof(c3));
+                c3.n = 1; c3.h_in = c3.w_in = c3.h_out = c3.w_out = cur_side; c3.c_in = c3.in_pix_stride = 64; c3.c_out = 256;
+                c3.kh = c3.kw = 1; c3.stride = 1; c3.dilation = 1; c3.out_dtype = c3.in_dtype = METRO_F16; c3.res_stride = 1;
+                chain_start = conv_pw64_supported(c3, 4);
+            }
+            const bool chain_mid = chain == 1 && u == 2 && conv1_done && !project && s == 1 && r == 1;
+            if (chain == 1 && !chain_mid) { set_error("internal: block1 rebuild chain planned for a unit 2 that is not plain"); return METRO_ERR_STATE; }
+            const int nxt_slot = chain_mid ? S_X1 : nxt;      // unit 2 of the chain: S_X0 still holds x0, which its launch reads
             const bool fuse_pair = fast && project && s == 1 && cout % 256 == 0 && cur_c % 64 == 0 && !unit_fused &&
                                    ((cb % 128 == 0 && cout <= 1024) || pw_pair);
             if (unit_fused) {
@@ -508,20 +530,58 @@ int build_plan(MetroPlan* p) {
             const int k_eff = 3 + 2 * (r - 1);
             const int pad_beg = (s == 1 || unit_centered) ? tf_same_pad_beg(cur_side, k_eff, s)
                                                           : (k_eff - 1) / 2;
-            B.add_conv(un + "/conv2", sc + "/conv2", sc + "/conv2/BatchNorm", "", S_T1, S_T2, S_NONE,
+            const int t2_slot = chain_start ? S_T2B : S_T2;   // unit 1 of the chain: its conv2 output is read again by unit 2's launch
+            B.add_conv(un + "/conv2", sc + "/conv2", sc + "/conv2/BatchNorm", "", S_T1, t2_slot, S_NONE,
                        cur_side, cb, side_out, cb, 3, s, r, pad_beg, true, 0, 1, 0, adt, adt);
             if (unit_fused) B.fuse_conv1_in_front(un, sc, cur, cur_side, cur_c, cb);
             // conv3 + bias + shortcut (resnet_v2.py:134-138)
             if (unit_fused) {
-                B.add_conv(un + "/conv3", sc + "/conv3", "", "", S_T2, nxt, S_NONE, side_out, cb, side_out, cout, 1, 1, 1, 0, false,
+                B.add_conv(un + "/conv3", sc + "/conv3", "", "", t2_slot, nxt, S_NONE, side_out, cb, side_out, cout, 1, 1, 1, 0, false,
                            0, 1, 0, adt, adt);
                 B.fuse_projection_shortcut(un, sc, cur, cur_side, cur_c, cout);
+                if (chain_start) {
+                    Layer& L3 = p->layers.back();
+                    L3.out_mode = 1;                                   // x_1 only feeds unit 2's conv1, inside this launch
+                    L3.info.fused_flags |= METRO_FUSED_OUT_ON_CHIP;
+                    chain = 1; chain_l1 = (int)p->layers.size() - 1; chain_x0 = cur;
+                }
+            } else if (chain_mid) {
+                // identity shortcut x_1 (resnet_v2.py:120-121 with stride 1) rebuilt in the launch: no residual tensor is read
+                B.add_conv(un + "/conv3", sc + "/conv3", "", "", S_T2, nxt_slot, S_NONE, side_out, cb, side_out, cout, 1, 1, 1, 0, false,
+                           0, 1, 0, adt, adt);
+                Layer& L3 = p->layers.back();
+                const Layer& L1 = p->layers[chain_l1];
+                L3.info.has_residual = 1; L3.info.res_stride = 1; L3.info.res_offset = 0;    // the reference's shortcut, as for any unit
+                L3.info.fused_flags |= METRO_FUSED_REBUILT_SHORTCUT;
+                L3.reb_w = L1.p_w; L3.reb_bias = L1.p_bias; L3.reb_slot = L1.in_slot;
+                L3.psc_w = L1.psc_w; L3.psc_bias = L1.psc_bias; L3.psc_scale = L1.psc_scale; L3.psc_shift = L1.psc_shift; L3.psc_slot = chain_x0;
+                // what the last unit reads of this sum: every pixel (it runs at stride 1: stride-4 nets), or every second one
+                const bool next_strided = (double)current_stride != output_stride;      // resnet_utils.py:325-333 for unit 3
+                if (next_strided) {
+                    L3.out_mode = 2; L3.sub_slot = S_X1; L3.sub_off = (b < 3 && centered[b]) ? 1 : 0; L3.sub_side = (cur_side + 1) / 2;
+                    L3.out_slot = S_SC;                                // metro_forward_upto stopping here writes the whole sum
+                    L3.info.fused_flags |= METRO_FUSED_OUT_ON_CHIP;
+                    B.need(S_SC, (int64_t)side_out * side_out * cout * aes);
+                    cur_compact = true;
+                }
+                chain = 2;
             } else if (project)
                 B.add_conv(un + "/conv3", sc + "/conv3", "", "", S_T2, nxt, S_SC, side_out, cb, side_out,
                            cout, 1, 1, 1, 0, false, side_out, 1, 0, adt, adt);
-            else
+            else {
                 B.add_conv(un + "/conv3", sc + "/conv3", "", "", S_T2, nxt, cur, side_out, cb, side_out,
                            cout, 1, 1, 1, 0, false, cur_side, s, shift, adt, adt);
+                if (cur_compact) {
+                    // the previous launch wrote exactly the pixels this unit's sub-sampled shortcut reads, compactly: the launch
+                    // adds them pixel for pixel (the info keeps the reference's gather: stride s, offset shift)
+                    if (s != 2) { set_error("internal: compact shortcut planned for a unit that is not strided"); return METRO_ERR_STATE; }
+                    Layer& L3 = p->layers.back();
+                    L3.cd.res_h = L3.cd.res_w = side_out; L3.cd.res_stride = 1; L3.cd.res_offset = 0;
+                    L3.info.fused_flags |= METRO_FUSED_COMPACT_SHORTCUT;
+                    cur_compact = false;
+                }
+                if (chain == 2) chain = 0;
+            }
             // block1 (full 256-channel rows per pixel tile): conv1 of the next unit rides in this launch
             if (fast && u < n_units[b] && s == 1) {
                 MetroConvDesc probe = p->layers.back().cd;
@@ -534,8 +594,9 @@ int build_plan(MetroPlan* p) {
                     conv1_done = true;
                 }
             }
-            cur = nxt; cur_side = side_out; cur_c = cout;
+            cur = nxt_slot; cur_side = side_out; cur_c = cout;
         }
+        if (chain != 0 || cur_compact) { set_error("internal: block%d ended inside a rebuild chain", b + 1); return METRO_ERR_STATE; }
     }
     if ((double)current_stride != output_stride) { set_error("The target output_stride cannot be reached."); return METRO_ERR_INVALID_ARG; }
     if (cur_side != sp.proc_side / sp.stride) { set_error("internal: output side %d != %d", cur_side, sp.proc_side / sp.stride); return METRO_ERR_STATE; }
@@ -552,7 +613,7 @@ int build_plan(MetroPlan* p) {
     {
         Layer L;
         memset(&L, 0, sizeof(L));
-        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE;
+        L.f2_w = L.f2_bias = L.f2_scale = L.f2_shift = -1; L.p1_w = L.p1_bias = L.p1_scale = L.p1_shift = -1; L.psc_w = L.psc_bias = L.psc_scale = L.psc_shift = -1; L.psc_slot = S_NONE; L.reb_w = L.reb_bias = -1; L.reb_slot = L.sub_slot = S_NONE;
         L.kind = LK_SOFTARGMAX;
         L.cd.h_in = L.cd.w_in = cur_side; L.cd.c_in = c_head; L.cd.h_out = 1; L.cd.w_out = sp.n_joints_out;
         L.cd.c_out = 3; L.cd.out_dtype = METRO_F32;
@@ -583,6 +644,9 @@ int build_plan(MetroPlan* p) {
     p->workspace_bytes = off;
     for (Layer& L : p->layers) {
         L.info.out_offset = L.out_slot >= 0 ? p->slot_offset[L.out_slot] : -1;
+        L.info.out_sub_offset = L.out_mode == 2 ? p->slot_offset[L.sub_slot] : -1;
+        L.info.out_sub_side = L.out_mode == 2 ? L.sub_side : 0;
+        L.info.out_sub_off = L.out_mode == 2 ? L.sub_off : 0;
         const int64_t es = L.cd.out_dtype == METRO_F16 ? 2 : L.cd.out_dtype == METRO_F32 ? 4 : 8;
         L.info.out_bytes_per_image = (int64_t)L.cd.h_out * L.cd.w_out * (L.split > 0 ? L.split : L.cd.c_out) * es;
         const bool two = L.kind == LK_CONV && (L.split > 0 || L.f2_w >= 0);
@@ -600,7 +664,9 @@ int build_plan(MetroPlan* p) {
         else if (L.kind == LK_CONV && L.cd.in_pix_stride != L.cd.c_in) act += (int64_t)L.cd.h_in * L.cd.w_in * L.cd.in_pix_stride * in_es;
         else act += (int64_t)L.cd.h_in * L.cd.w_in * L.cd.c_in * in_es;
         if (L.kind == LK_SOFTARGMAX) act += (int64_t)sp.n_joints_out * 3 * 4;
-        else act += L.info.out_bytes_per_image;
+        else if (L.out_mode == 0) act += L.info.out_bytes_per_image;
+        else if (L.out_mode == 2) act += (int64_t)L.sub_side * L.sub_side * L.cd.c_out * es;     // the sub-sampled copy only
+        if (L.reb_w >= 0) act += (int64_t)L.cd.h_out * L.cd.w_out * p->params[L.reb_w].c_in * es;  // the previous unit's conv2 output
         if (two) act += (int64_t)L.cd.h_out * L.cd.w_out * L.info.out2_channels * es;
         if (L.kind == LK_CONV && L.cd.has_residual) act += (int64_t)L.cd.h_out * L.cd.w_out * L.cd.c_out * es;
         if (L.psc_w >= 0) act += (int64_t)L.cd.h_out * L.cd.w_out * p->params[L.psc_w].c_in * es;      // the unit input, read for the shortcut
@@ -612,7 +678,7 @@ int build_plan(MetroPlan* p) {
         L.info.algo_act_bytes_per_image = act;
         int64_t pb = 0;
         for (int idx : {L.p_w, L.p_bias, L.p_scale, L.p_shift, L.f2_w, L.f2_bias, L.f2_scale, L.f2_shift, L.p1_w, L.p1_bias, L.p1_scale,
-                        L.p1_shift, L.psc_w, L.psc_bias, L.psc_scale, L.psc_shift})
+                        L.p1_shift, L.psc_w, L.psc_bias, L.psc_scale, L.psc_shift, L.reb_w, L.reb_bias})
             if (idx >= 0) pb += p->params[idx].bytes;
         if (L.split > 0) pb += p->params[L.p_w + 1].bytes + p->params[L.p_bias + 1].bytes;   // conv1 rows of a fused pair
         L.info.algo_param_bytes = pb;
@@ -666,9 +732,18 @@ int launch_layer(const MetroPlan* p, const char* d_params, int li, const float* 
                     ps.x = slot_ptr(L.psc_slot); ps.w_sc = prm(L.psc_w); ps.bias_sc = static_cast<const float*>(prm(L.psc_bias));
                     ps.pro_scale = prm(L.psc_scale); ps.pro_shift = prm(L.psc_shift);
                 }
+                // block1 without its residual stream in HBM: metro_forward_upto stopping here (dump) stores the sum in full
+                ConvRebuild rb;
+                const bool has_rb = L.reb_w >= 0 || L.out_mode != 0;
+                if (L.reb_w >= 0) {
+                    rb.t2_prev = slot_ptr(L.reb_slot); rb.w3_prev = prm(L.reb_w); rb.bias3_prev = static_cast<const float*>(prm(L.reb_bias));
+                }
+                rb.out_mode = dump ? 0 : L.out_mode;
+                rb.classic = dump ? 1 : 0;
+                if (rb.out_mode == 2) { rb.out_sub = slot_ptr(L.sub_slot); rb.sub_off = L.sub_off; rb.h_sub = rb.w_sub = L.sub_side; }
                 return launch_conv_f16_dma(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
                                            nullptr, nullptr, slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream, nullptr, &f2,
-                                           L.psc_w >= 0 ? &ps : nullptr);
+                                           L.psc_w >= 0 ? &ps : nullptr, has_rb ? &rb : nullptr);
             }
             if (p->fast && L.p1_w >= 0) {
                 ConvPre1 p1;
@@ -984,7 +1059,7 @@ int metro_conv_f16_next_proj(const MetroConvDesc* d, const void* d_in, const voi
                              int32_t c2, void* stream) {
     int st = validate_conv_desc(d);
     if (st) return st;
-    METRO_CHECK_ARG(d_in && d_w && d_bias && d_x && d_w_sc && d_bias_sc && d_pro_scale && d_pro_shift && d_out && d_w2 && d_bias2 &&
+    METRO_CHECK_ARG(d_in && d_w && d_bias && d_x && d_w_sc && d_bias_sc && d_pro_scale && d_pro_shift && d_w2 && d_bias2 &&
                         d_scale2 && d_shift2 && d_out2, "conv_f16_next_proj: NULL tensor pointer");
     METRO_CHECK_ARG(conv_pw64_supported(*d, 3) && c2 == 64, "conv_f16_next_proj: built for 1x1 stride-1 64 -> 256 without prologue / residual, "
                     "c2 = 64 (block1/unit_1), fp16");
@@ -992,7 +1067,43 @@ int metro_conv_f16_next_proj(const MetroConvDesc* d, const void* d_in, const voi
     f2.w2 = d_w2; f2.bias2 = d_bias2; f2.scale2 = d_scale2; f2.shift2 = d_shift2; f2.out2 = d_out2; f2.c2 = c2;
     ConvProjSc ps;
     ps.x = d_x; ps.w_sc = d_w_sc; ps.bias_sc = d_bias_sc; ps.pro_scale = d_pro_scale; ps.pro_shift = d_pro_shift;
-    return launch_conv_f16_dma(*d, d_in, d_w, d_bias, nullptr, nullptr, nullptr, d_out, static_cast<hipStream_t>(stream), nullptr, &f2, &ps);
+    ConvRebuild rb;
+    rb.out_mode = d_out == nullptr ? 1 : 0;          // d_out == NULL: the sum stays on chip (it only feeds the second GEMM)
+    return launch_conv_f16_dma(*d, d_in, d_w, d_bias, nullptr, nullptr, nullptr, d_out, static_cast<hipStream_t>(stream), nullptr, &f2, &ps,
+                               d_out == nullptr ? &rb : nullptr);
+}
+
+int metro_conv_f16_next_rebuild(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias, const void* d_x,
+                                const void* d_w_sc, const float* d_bias_sc, const void* d_pro_scale, const void* d_pro_shift,
+                                const void* d_t2_prev, const void* d_w3_prev, const float* d_bias3_prev, void* d_out, void* d_out_sub,
+                                int32_t sub_off, const void* d_w2, const float* d_bias2, const void* d_scale2, const void* d_shift2,
+                                void* d_out2, int32_t c2, void* stream) {
+    int st = validate_conv_desc(d);
+    if (st) return st;
+    METRO_CHECK_ARG(d_in && d_w && d_bias && d_x && d_w_sc && d_bias_sc && d_pro_scale && d_pro_shift && d_t2_prev && d_w3_prev && d_bias3_prev &&
+                        d_w2 && d_bias2 && d_scale2 && d_shift2 && d_out2, "conv_f16_next_rebuild: NULL tensor pointer");
+    METRO_CHECK_ARG((d_out != nullptr) != (d_out_sub != nullptr), "conv_f16_next_rebuild: exactly one of d_out (the whole sum) and d_out_sub (its "
+                    "sub-sampled compact copy) must be given");
+    METRO_CHECK_ARG(sub_off == 0 || sub_off == 1, "conv_f16_next_rebuild: sub_off %d must be 0 or 1", sub_off);
+    METRO_CHECK_ARG(conv_pw64_supported(*d, 4) && c2 == 64, "conv_f16_next_rebuild: built for 1x1 stride-1 64 -> 256 without prologue / residual on maps "
+                    "whose width is a power of two >= 16 and whose pixel count is a multiple of 64, c2 = 64 (block1/unit_2), fp16");
+    ConvFuse2 f2;
+    f2.w2 = d_w2; f2.bias2 = d_bias2; f2.scale2 = d_scale2; f2.shift2 = d_shift2; f2.out2 = d_out2; f2.c2 = c2;
+    ConvProjSc ps;
+    ps.x = d_x; ps.w_sc = d_w_sc; ps.bias_sc = d_bias_sc; ps.pro_scale = d_pro_scale; ps.pro_shift = d_pro_shift;
+    ConvRebuild rb;
+    rb.t2_prev = d_t2_prev; rb.w3_prev = d_w3_prev; rb.bias3_prev = d_bias3_prev;
+    if (d_out_sub != nullptr) {
+        rb.out_mode = 2; rb.out_sub = d_out_sub; rb.sub_off = sub_off;
+        rb.h_sub = (d->h_out - sub_off + 1) / 2; rb.w_sub = (d->w_out - sub_off + 1) / 2;
+    }
+    return launch_conv_f16_dma(*d, d_in, d_w, d_bias, nullptr, nullptr, nullptr, d_out, static_cast<hipStream_t>(stream), nullptr, &f2, &ps, &rb);
+}
+
+int metro_conv_b1_form(int32_t classic) {
+    METRO_CHECK_ARG(classic == 0 || classic == 1, "metro_conv_b1_form: 0 (default dispatch) or 1 (classic single-role kernel)");
+    conv_b1_set_form(classic);
+    return METRO_OK;
 }
 
 int metro_conv_f16_gemm4w(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,

@@ -105,7 +105,9 @@ def test_planner_agrees_with_oracle_schedule(arch, stride, centered, prec):
             c12, c3 = layers[f'{u.name}/conv1+conv2'], layers[f'{u.name}/conv3']
             assert prec == 'f16' and u.c_in == 64 and u.c_out == 256 and u.stride == 1 and u.rate == 1
             assert not any(f'{u.name}/{k}' in layers for k in ('conv1', 'conv2', 'shortcut', 'shortcut+conv1'))
-            assert c12.fused_flags == _lib.FUSED_CONV1_IN_FRONT and c3.fused_flags == _lib.FUSED_PROJECTION_SHORTCUT
+            # ... and (round 5) the unit's 256-channel sum stays on chip: it only feeds unit 2's conv1 in the same launch
+            assert c12.fused_flags == _lib.FUSED_CONV1_IN_FRONT
+            assert c3.fused_flags == _lib.FUSED_PROJECTION_SHORTCUT | _lib.FUSED_OUT_ON_CHIP
             assert (c12.kh, c12.stride, c12.dilation, c12.c_in, c12.c_out, c12.h_in, c12.h_out, c12.pad_top, c12.relu) == \
                 (3, 1, 1, u.c_in, u.c_bott, u.side_in, u.side_out, 1, 1)
             assert abs(c12.flops_per_image - 2.0 * u.side_in ** 2 * u.c_bott * (9 * u.c_bott + u.c_in)) < 1
@@ -120,6 +122,18 @@ def test_planner_agrees_with_oracle_schedule(arch, stride, centered, prec):
             assert (host.out2_channels, host.h_out, host.kh, host.stride) == (u.c_bott, u.side_in, 1, 1)
             assert host.out2_offset >= 0 and host.out2_offset != host.out_offset
             assert (c2.kh, c2.stride, c2.dilation, c2.h_in, c2.h_out, c2.c_out) == (3, u.stride, u.rate, u.side_in, u.side_out, u.c_bott)
+            if c3.fused_flags & _lib.FUSED_REBUILT_SHORTCUT:
+                # block1/unit_2 (round 5): the identity shortcut is rebuilt in the launch; the info still states the reference's
+                # shortcut; where unit 3 is strided only the pixels ITS shortcut reads are written (compact copy), else the sum
+                assert u.name == 'block1/unit_2' and (c3.has_residual, c3.res_stride, c3.res_offset) == (1, 1, 0)
+                u3 = units[units.index(u) + 1]
+                if u3.stride == 2:
+                    assert c3.fused_flags & _lib.FUSED_OUT_ON_CHIP and c3.out_sub_offset >= 0
+                    assert (c3.out_sub_side, c3.out_sub_off) == (u3.side_out, 1 if u3.centered else 0)
+                    assert layers['block1/unit_3/conv3'].fused_flags == _lib.FUSED_COMPACT_SHORTCUT
+                else:
+                    assert not (c3.fused_flags & _lib.FUSED_OUT_ON_CHIP) and c3.out_sub_offset == -1
+                    assert layers['block1/unit_3/conv3'].fused_flags == 0
             continue
         if f'{u.name}/shortcut+conv1' in layers:
             # fp16 plans fuse the projection shortcut and conv1 of a unit (same pre-activated input)

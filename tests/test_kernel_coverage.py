@@ -232,10 +232,14 @@ def _conv(lib, cuda, li, n, gen, rng, dev, kid, name):
     k, h_in, h_out = li.kh, li.h_in, li.h_out
     assert li.kh == li.kw and li.h_in == li.w_in and li.pad_top == li.pad_left
     f32out = li.out_dtype == _lib.METRO_F32
-    res_h = h_out if li.res_stride == 1 else 2 * h_out
+    rebuilt = bool(li.fused_flags & _lib.FUSED_REBUILT_SHORTCUT)      # the shortcut is rebuilt in the launch: no residual tensor
+    compact = bool(li.fused_flags & _lib.FUSED_COMPACT_SHORTCUT)      # the sub-sampled shortcut arrives as a compact tensor
+    has_res = bool(li.has_residual) and not rebuilt
+    res_stride, res_offset = (1, 0) if compact else (li.res_stride, li.res_offset)
+    res_h = h_out if res_stride == 1 else 2 * h_out
     d = H.conv_desc(n, h_in, c_in, h_out, c_out, k, li.stride, li.dilation, li.pad_top, prologue=bool(li.has_prologue),
-                    relu=bool(li.relu), residual=bool(li.has_residual), res_h=res_h, res_stride=li.res_stride,
-                    res_offset=li.res_offset, out_dtype=_lib.METRO_F32 if f32out else _lib.METRO_F16, in_dtype=_lib.METRO_F16)
+                    relu=bool(li.relu), residual=has_res, res_h=res_h, res_stride=res_stride,
+                    res_offset=res_offset, out_dtype=_lib.METRO_F32 if f32out else _lib.METRO_F16, in_dtype=_lib.METRO_F16)
     x, xb = _periodic(gen, n, (h_in, h_in, c_in), cuda, relu=not li.has_prologue and k == 3)
     w = (rng.standard_normal((c_out, k, k, c_in)) * np.sqrt(2.0 / (k * k * c_in))).astype(np.float16)
     b = (rng.standard_normal(c_out) * 0.1).astype(np.float32)
@@ -246,14 +250,14 @@ def _conv(lib, cuda, li, n, gen, rng, dev, kid, name):
         pro = (rng.uniform(0.5, 1.5, c_in).astype(np.float16), (rng.standard_normal(c_in) * 0.2).astype(np.float16))
         ts, tsh = dev(pro[0], np.float16), dev(pro[1], np.float16)
     rb = None
-    if li.has_residual:
+    if has_res:
         tr, rb = _periodic(gen, n, (res_h, res_h, c_out), cuda)
     out = torch.full((n, h_out, h_out, c1), float('nan'), dtype=torch.float32 if f32out else torch.float16, device=cuda)
     out2 = None
     if li.fused_flags & _lib.FUSED_CONV1_IN_FRONT:
         return _conv1_conv2(lib, cuda, li, n, d, x, xb, tw, tb, w, b, out, rng, dev, kid)
     psc = None
-    if li.fused_flags & _lib.FUSED_PROJECTION_SHORTCUT:
+    if li.fused_flags & (_lib.FUSED_PROJECTION_SHORTCUT | _lib.FUSED_REBUILT_SHORTCUT):
         assert nxt, 'the in-launch projection shortcut exists in the conv3 + next conv1 launch only'
         cx = 64                                   # the unit's raw input (block1/unit_1: the pooled stem output)
         xs, xsb = _periodic(gen, n, (h_out, h_out, cx), cuda)
@@ -274,10 +278,61 @@ def _conv(lib, cuda, li, n, gen, rng, dev, kid, name):
         sh2 = (rng.standard_normal(c1) * 0.2).astype(np.float16)
         t2 = [dev(w2, np.float16), dev(b2, np.float32), dev(sc2, np.float16), dev(sh2, np.float16)]
         out2 = torch.full((n, h_out, h_out, c2), float('nan'), dtype=torch.float16, device=cuda)
-        if psc is not None:
-            check(lib.metro_conv_f16_next_proj(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(psc[0]), H.ptr(psc[1]), H.ptr(psc[2]),
-                                               H.ptr(psc[3]), H.ptr(psc[4]), H.ptr(out), H.ptr(t2[0]), H.ptr(t2[1]), H.ptr(t2[2]),
-                                               H.ptr(t2[3]), H.ptr(out2), c2, None), 'metro_conv_f16_next_proj')
+        on_chip = bool(li.fused_flags & _lib.FUSED_OUT_ON_CHIP)
+        prev = None
+        if rebuilt:
+            # block1/unit_2: x_1 = fp16(W3_prev . t2_prev + b) + fp16(Wsc . pre(x0) + bsc) is rebuilt in the launch.  The storing form
+            # (what metro_forward_upto runs) gives `out`; the form the plan names must give the SAME second output, and its
+            # sub-sampled copy must be those pixels of `out`
+            tp, tpb = _periodic(gen, n, (h_out, h_out, 64), cuda, relu=True)
+            w3p = (rng.standard_normal((c1, 64)) * np.sqrt(2.0 / 64)).astype(np.float16)
+            b3p = (rng.standard_normal(c1) * 0.1).astype(np.float32)
+            prev = [tp, dev(w3p, np.float16), dev(b3p, np.float32)]
+            args = lambda o, osub, soff, o2: (C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(psc[0]), H.ptr(psc[1]), H.ptr(psc[2]), H.ptr(psc[3]),
+                                              H.ptr(psc[4]), H.ptr(prev[0]), H.ptr(prev[1]), H.ptr(prev[2]), H.ptr(o), H.ptr(osub), soff, H.ptr(t2[0]),
+                                              H.ptr(t2[1]), H.ptr(t2[2]), H.ptr(t2[3]), H.ptr(o2), c2, None)
+            # the classic single-role kernel first (what metro_forward_upto runs: the whole sum stored) ...
+            check(lib.metro_conv_b1_form(1), 'metro_conv_b1_form')
+            try:
+                check(lib.metro_conv_f16_next_rebuild(*args(out, None, 0, out2)), 'metro_conv_f16_next_rebuild (classic form)')
+                torch.cuda.synchronize()
+            finally:
+                lib.metro_conv_b1_form(0)
+            full, full2 = out.clone(), out2.clone()
+            # ... then the form the plan names: same sum (or exactly its sub-sampled pixels), same second output, bit for bit
+            check(lib.metro_kernel_notes(1), 'metro_kernel_notes')
+            out.fill_(float('nan'))
+            out2.fill_(float('nan'))
+            if li.out_sub_offset >= 0:
+                sub = torch.full((n, li.out_sub_side, li.out_sub_side, c1), float('nan'), dtype=torch.float16, device=cuda)
+                check(lib.metro_conv_f16_next_rebuild(*args(None, sub, li.out_sub_off, out2)), 'metro_conv_f16_next_rebuild')
+                torch.cuda.synchronize()
+                o = li.out_sub_off
+                assert torch.equal(sub, full[:, o::2, o::2][:, :li.out_sub_side, :li.out_sub_side]), f'{kid}: sub-sampled copy != pixels of the classic form\'s sum'
+                out.copy_(full)
+            else:
+                check(lib.metro_conv_f16_next_rebuild(*args(out, None, 0, out2)), 'metro_conv_f16_next_rebuild')
+                torch.cuda.synchronize()
+                assert torch.equal(out, full), f'{kid}: the sum differs between the classic and the producer / consumer form'
+            assert torch.equal(out2, full2), f'{kid}: second output differs between the classic and the producer / consumer form'
+        elif psc is not None:
+            pargs = lambda o, o2: (C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(psc[0]), H.ptr(psc[1]), H.ptr(psc[2]), H.ptr(psc[3]), H.ptr(psc[4]),
+                                   H.ptr(o), H.ptr(t2[0]), H.ptr(t2[1]), H.ptr(t2[2]), H.ptr(t2[3]), H.ptr(o2), c2, None)
+            if on_chip:           # the plan's form keeps the sum on chip: same second output as the classic storing form
+                check(lib.metro_conv_b1_form(1), 'metro_conv_b1_form')
+                try:
+                    check(lib.metro_conv_f16_next_proj(*pargs(out, out2)), 'metro_conv_f16_next_proj (classic form)')
+                    torch.cuda.synchronize()
+                finally:
+                    lib.metro_conv_b1_form(0)
+                full2 = out2.clone()
+                check(lib.metro_kernel_notes(1), 'metro_kernel_notes')
+                out2.fill_(float('nan'))
+                check(lib.metro_conv_f16_next_proj(*pargs(None, out2)), 'metro_conv_f16_next_proj (sum on chip)')
+                torch.cuda.synchronize()
+                assert torch.equal(out2, full2), f'{kid}: second output differs between the classic storing and the on-chip form'
+            else:
+                check(lib.metro_conv_f16_next_proj(*pargs(out, out2)), 'metro_conv_f16_next_proj')
         else:
             check(lib.metro_conv_f16_next(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(tr), H.ptr(out), H.ptr(t2[0]), H.ptr(t2[1]),
                                           H.ptr(t2[2]), H.ptr(t2[3]), H.ptr(out2), c2, None), 'metro_conv_f16_next')
@@ -300,11 +355,14 @@ def _conv(lib, cuda, li, n, gen, rng, dev, kid, name):
         _close(out2[:p].cpu().numpy(), np.maximum(ref[..., c1:], 0), kid + ' (second output)')
         return
     if rb is not None:        # fp16(conv + bias), then the fp16 Add of the (sub-sampled, shifted) shortcut
-        r = rb.astype(np.float64)[:, li.res_offset::li.res_stride, li.res_offset::li.res_stride][:, :h_out, :h_out]
+        r = rb.astype(np.float64)[:, res_offset::res_stride, res_offset::res_stride][:, :h_out, :h_out]
         ref = ref.astype(np.float16).astype(np.float64) + r
     if psc is not None:       # fp16(conv3 + bias) + fp16(Wsc . fp16(relu(x * s + b)) + bias_sc): the fp16 Add of resnet_v2.py:138
         xin_s = np.maximum((xsb.astype(np.float64) * psc_s.astype(np.float64) + psc_b.astype(np.float64)).astype(np.float16).astype(np.float64), 0)
         sc = (xin_s @ wsc.astype(np.float64).T + bsc.astype(np.float64)).astype(np.float16).astype(np.float64)
+        if rebuilt:           # x_1 = fp16(fp16(W3_prev . t2_prev + b) + projection shortcut), then THIS unit's fp16 Add
+            c3p = (tpb.astype(np.float64) @ w3p.astype(np.float64).T + b3p.astype(np.float64)).astype(np.float16).astype(np.float64)
+            sc = (c3p + sc).astype(np.float16).astype(np.float64)
         ref = ref.astype(np.float16).astype(np.float64) + sc
     _close(got, ref, kid, tol=2e-5 if f32out else 2e-3)
     if nxt:

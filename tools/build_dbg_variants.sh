@@ -1,21 +1,21 @@
 #!/bin/bash
 # Timing-experiment builds of the library with parts of one kernel compiled out (results are garbage):
-#   tools/build_dbg_variants.sh <source.hip> MACRO [MACRO...]   ->  metro_pose3d_amd/dbg/libmetro_<MACRO>.so
-# use with METRO_HIP_LIB=$PWD/metro_pose3d_amd/dbg/libmetro_<MACRO>.so python bench.py --layer-report ...
+#   tools/build_dbg_variants.sh <source.hip> MACRO [MACRO...]   ->  metro_pose3d_amd/ab/libmetro_<MACRO>.so
+# use with METRO_HIP_LIB=$PWD/metro_pose3d_amd/ab/libmetro_<MACRO>.so python bench.py --layer-report ...
 set -e
 cd "$(dirname "$0")/.."
 python -m metro_pose3d_amd.build >/dev/null
 cd metro_pose3d_amd
 src=$1; shift
 stem=$(basename "$src" .hip)
-mkdir -p dbg
+mkdir -p ab
 for v in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Wno-unused-function $(echo $v | tr "+" "\n" | sed "s/^/-DMETRO_DBG_/" | tr "\n" " ") -I../include \
-      -c csrc/$stem.hip -o dbg/${stem}_$v.o &
+      -c csrc/$stem.hip -o ab/${stem}_$v.o &
 done
 wait
 for v in "$@"; do
   objs=$(ls build/*.o | grep -v "/$stem.o")
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o dbg/libmetro_$v.so $objs dbg/${stem}_$v.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/libmetro_$v.so $objs ab/${stem}_$v.o
 done
-ls dbg/*.so
+ls ab/*.so
