@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_PATH = os.path.join(HERE, 'libmetro_hip.so')
-SOURCES = ['conv_igemm_f16_dma.hip', 'conv_gemm4w.hip', 'conv3x3_f16_slab.hip', 'conv3x3_c64.hip', 'conv_pw64.hip', 'conv_b1.hip', 'head_f16.hip', 'stem_pool_f16.hip', 'conv_igemm_f64acc.hip', 'conv_igemm_f32.hip', 'pool_softargmax.hip', 'eval_metrics.hip', 'heads.hip', 'plan.cpp']
+SOURCES = ['conv_igemm_f16_dma.hip', 'conv_gemm4w.hip', 'conv3x3_f16_slab.hip', 'conv3x3_c64.hip', 'conv_pw64.hip', 'conv_b1.hip', 'conv_pws.hip', 'head_f16.hip', 'stem_pool_f16.hip', 'conv_igemm_f64acc.hip', 'conv_igemm_f32.hip', 'pool_softargmax.hip', 'eval_metrics.hip', 'heads.hip', 'plan.cpp']
 EXPERIMENTAL_LIB_PATH = os.path.join(HERE, 'libmetro_experimental.so')
 EXPERIMENTAL_SOURCES = [os.path.join('experimental', f) for f in ('conv_gemm8p.hip', 'conv_gemm4d.hip', 'exp_abi.cpp')]
 EXPERIMENTAL_HEADERS = [os.path.join('experimental', 'metro_experimental.h')]

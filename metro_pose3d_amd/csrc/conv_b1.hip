@@ -358,6 +358,7 @@ __global__ __launch_bounds__(b1::NT) void conv_b1_chain_kernel(B1Args a) {
 // thread-local test switch (metro_conv_b1_form): 1 = always the classic single-role kernel of conv_pw64.hip
 static thread_local int g_b1_force_classic = 0;
 void conv_b1_set_form(int classic) { g_b1_force_classic = classic; }
+bool classic_forms_forced() { return g_b1_force_classic != 0; }
 
 bool conv_b1_chain_preferred() {
     static const int enabled = tuning_knob("METRO_B1_SPLIT", 1);

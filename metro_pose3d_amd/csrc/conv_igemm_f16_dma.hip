@@ -711,6 +711,8 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
         set_error("conv3 with an in-launch projection shortcut: built for 1x1 stride-1 64 -> 256 + next conv1 (block1/unit_1) only");
         return METRO_ERR_UNSUPPORTED;
     }
+    if (!(fuse2 != nullptr && fuse2->w2 != nullptr) && !(split != nullptr && split->split > 0) && conv_pws_supported(d))
+        return launch_conv_pws(d, in_, w_, bias, res_, out, stream);
     {
         const int mode = (fuse2 != nullptr && fuse2->w2 != nullptr) ? 2 : (split != nullptr && split->split > 0) ? 1 : 0;
         if (conv_pw64_supported(d, mode) && (mode != 1 || (split->split == 256 && split->c_out2 == 64 && split->relu2 == 1)) &&

@@ -254,7 +254,11 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
                      const ConvRebuild* rebuild = nullptr);
 // producer / consumer form of the conv3 + next conv1 launches of block1 whose sum stays on chip (conv_b1.hip)
 bool conv_b1_chain_preferred();
-void conv_b1_set_form(int classic);      // thread-local test switch: 1 = never dispatch it
+void conv_b1_set_form(int classic);      // thread-local test switch: 1 = never dispatch it (nor conv_pws.hip's kernel)
+bool classic_forms_forced();
+// conv3 + shortcut of blocks 3-4 with the two waves of a SIMD half a tile apart (conv_pws.hip); same bits as conv_pw64's <k256|k512,wm8,res>
+bool conv_pws_supported(const MetroConvDesc& d);
+int launch_conv_pws(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* res, void* out, hipStream_t stream);
 int launch_conv_b1_chain(const MetroConvDesc& d, const void* in, const void* w, const float* bias, void* out, hipStream_t stream,
                          const ConvFuse2& f2, const ConvProjSc& psc, const ConvRebuild& rb);
 // stem 7x7/2 conv + zero-padded 3x3/2 max-pool in one persistent kernel (stem_pool_f16.hip); input is the

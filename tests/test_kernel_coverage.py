@@ -339,6 +339,21 @@ def _conv(lib, cuda, li, n, gen, rng, dev, kid, name):
     else:
         check(lib.metro_conv_f16(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr), H.ptr(out), None),
               'metro_conv_f16')
+        if kid.startswith('conv_pws<'):        # the skewed kernel and conv_pw64's lock-step one: the same bits
+            torch.cuda.synchronize()
+            skewed = out.clone()
+            noted = _noted(lib)
+            check(lib.metro_conv_b1_form(1), 'metro_conv_b1_form')
+            try:
+                check(lib.metro_conv_f16(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr), H.ptr(out), None),
+                      'metro_conv_f16 (classic form)')
+                torch.cuda.synchronize()
+            finally:
+                lib.metro_conv_b1_form(0)
+            assert _noted(lib)[-1].startswith('conv_pw64<'), _noted(lib)
+            assert torch.equal(out, skewed), f'{kid}: differs from {_noted(lib)[-1]}'
+            check(lib.metro_kernel_notes(1), 'metro_kernel_notes')
+            check(lib.metro_conv_f16(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr), H.ptr(out), None), 'metro_conv_f16')
     torch.cuda.synchronize()
     assert _noted(lib) == [kid], f'the entry point launched {_noted(lib)}, the plan names {kid}'
     _assert_periodic(out, n, kid)
