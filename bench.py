@@ -25,6 +25,7 @@ One JSON line on stdout from rank 0, with
   parity_mode  -- crops/s of the f64 parity mode on the same batch (outside the timed region);
   b256         -- (N = 1) the same workload at batch 256, the batch BASELINE.json's north star
                   quotes its roofline target on: crops/s, ms/step and its own roofline object;
+  merged53     -- (N = 1) RN50-s16 with the 53-joint head of the released many_* exports, batch 64 (next to c3_shard);
   c3_shard, c4_shard, c5_shard -- (N = 1) one GPU's shard of BASELINE.json configs[2..4] (RN50-s16-J19
                   batch 512/8, RN101-s8-J19 batch 256/8, RN50-s4-J17 batch 128/8), each with its roofline;
   boundary     -- 256 crops through `estimate_pose` itself (the drop-in call of reference inference.py:31-43, model file ->
@@ -613,6 +614,9 @@ def main():
             out['c3_shard'] = side_workload(device, dist, 50, 16, 'many19', 64, 20, 3, 'configs[2]: batch 512 sharded over 8 GPUs')
             out['c4_shard'] = side_workload(device, dist, 101, 8, 'many19', 32, 10, 3, 'configs[3]: batch 256 sharded over 8 GPUs')
             out['c5_shard'] = side_workload(device, dist, 50, 4, 'h36m', 16, 10, 3, 'configs[4]: batch 128 sharded over 8 GPUs')
+            # the released `many_*` exports carry the 53-joint `merged` head (424 channels; reference data/datasets.py:142-154,
+            # main.py:119-127): since round 5 on the one-launch head too (three joint groups), logits on chip
+            out['merged53'] = side_workload(device, dist, 50, 16, 'merged', 64, 20, 3, 'the 53-joint head of the released many_* exports (not a BASELINE config)')
             out['boundary'] = boundary_leg(device, dist, spec, params, 256, 10, 2)
             # the HBM-bound number SURVEY 8(d) asks for next to the MFMA one: the soft-argmax on its own
             out['softargmax_hbm'] = {'note': 'pure-read launch: 2 x FETCH only.  Yardsticks on the same 285 MB on this chip (tools/hbm_read_probe.py, '

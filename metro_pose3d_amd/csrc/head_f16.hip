@@ -69,6 +69,11 @@ struct HeadArgs {
     float* partials;          // [n][slabs][J][5]: m, S, Sx, Sy, Sz
     float* logits_out;        // optional fp32 NHWC logits [n * pixels][C] (tests / layer dumps); NULL in the product path
     int K, C, J, D, side, pixels, slabs;
+    // Heads wider than 160 channels (the 53-joint `merged` export: 424, reference data/datasets.py:142-154, main.py:119-127) run the
+    // ring kernel once per GROUP of JG joints (blockIdx.z): a group's sub-head is the D * jg rows d * J + j0 + j' of the weight
+    // matrix (all depths of its joints: the softmax of a joint needs nothing else), gathered row by row by the LDS-DMA sources,
+    // its logits tile is [32][D * jg] in the same (d, j') order and its records go to joints j0 .. j0 + jg - 1.  JG = 0: one group.
+    int JG;
 };
 
 __global__ __launch_bounds__(hd::NT) void head_f16_kernel(HeadArgs a) {
@@ -577,6 +582,17 @@ __global__ __launch_bounds__(512, 2) void head_f16_ring_kernel(HeadArgs a) {
     const int K = a.K, nk = K / BK;
     const unsigned smem_base = (unsigned)(size_t)(hd_lds_void_t*)smem;
     half_t* pro_lds = reinterpret_cast<half_t*>(smem + G::PRO_OFF);
+    // joint group of this block: joints j0 .. j0 + jg - 1, sub-head rows c' = d * jg + j' <-> weight / bias row d * J + j0 + j'
+    const int j0 = a.JG > 0 ? (int)blockIdx.z * a.JG : 0;
+    const int jg = a.JG > 0 ? (a.J - j0 < a.JG ? a.J - j0 : a.JG) : a.J;
+    const int cg = jg * a.D;                               // channels of the sub-head
+    auto src_row = [&](int c) { return a.JG > 0 ? (c / jg) * a.J + j0 + c % jg : c; };
+    if (a.JG > 0) {
+        // the bias of a sub-head is a gather: ordinary loads, FIRST (the compiler waits for them with vmcnt(0): nothing of the ring is
+        // in flight yet), visible behind the prologue's barrier
+        float* bl = reinterpret_cast<float*>(smem + G::BIAS_OFF);
+        if (tid < 256) bl[tid] = tid < cg ? a.bias[src_row(tid)] : 0.f;
+    }
 
     // ---- DMA sources per K step (one instruction = 8 rows x 128 B, lane: row l >> 3, physical chunk l & 7): pixel groups
     //      wave + 8 i (NB each), weight groups wave + 8 i < GA (the first GA % 8 waves issue one more).  Rows past the head's
@@ -588,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void head_f16_ring_kernel(HeadArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int row = (wave + NW * i) * 8 + lrow;
-        const int srow = row < a.C ? row : a.C - 1;
+        const int srow = src_row(row < cg ? row : cg - 1);
         voffw[i] = (unsigned)(srow * K + ((lch ^ hd_swz(row)) * 8)) * 2u;
     }
 #pragma unroll
@@ -633,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void head_f16_ring_kernel(HeadArgs a) {
         const int idx = (wave & 3) * 512 + lane * 8;
         const unsigned dst = __builtin_amdgcn_readfirstlane(smem_base + G::PRO_OFF + (wave >> 2) * 4096 + (wave & 3) * 1024);
         hd_dma16s<0>(wave < 4 ? a.pro_scale : a.pro_shift, (unsigned)((idx < K ? idx : 0) * 2), dst);
-        hd_dma16s<0>(a.bias, (unsigned)((lane * 4 < a.C ? lane * 4 : 0) * 4), smem_base + G::BIAS_OFF);
+        if (a.JG == 0) hd_dma16s<0>(a.bias, (unsigned)((lane * 4 < a.C ? lane * 4 : 0) * 4), smem_base + G::BIAS_OFF);
     }
 #pragma unroll
     for (int st = 0; st < STAGES; ++st) issue_step(st * STAGE_BYTES, st < nk ? st : nk - 1);
@@ -805,17 +821,17 @@ __global__ __launch_bounds__(512, 2) void head_f16_ring_kernel(HeadArgs a) {
         __syncthreads();
         const int p0 = (pg * PT + t) * 32;                        // first pixel of the tile inside the block
         if (a.logits_out != nullptr) {
-            for (int idx = h * 64 + lane; idx < 32 * a.C; idx += KSPLIT * 64) {
-                const int p = idx / a.C, c = idx - p * a.C;
-                a.logits_out[(size_t)(m0 + p0 + p) * a.C + c] = lt0[p * LROW + c];
+            for (int idx = h * 64 + lane; idx < 32 * cg; idx += KSPLIT * 64) {
+                const int p = idx / cg, c = idx - p * cg;
+                a.logits_out[(size_t)(m0 + p0 + p) * a.C + src_row(c)] = lt0[p * LROW + c];
             }
         }
         const int pim = tile * TN + p0 + frag_row;                // pixel index inside the image
         const int py = pim / a.side, px = pim - py * a.side;
         const float cx = (float)px * step_s, cy = (float)py * step_s;
         const int slab = tile * (TN / 32) + pg * PT + t;
-        float* rec = a.partials + ((size_t)img * a.slabs + slab) * a.J * 5;
-        hd_tile_stats(lt0 + frag_row * LROW, a.J, a.D, h * 2 + frag_half, 2 * KSPLIT, cx, cy, step_d, frag_row == 0,
+        float* rec = a.partials + (((size_t)img * a.slabs + slab) * a.J + j0) * 5;
+        hd_tile_stats(lt0 + frag_row * LROW, jg, a.D, h * 2 + frag_half, 2 * KSPLIT, cx, cy, step_d, frag_row == 0,
                       [&](int j, float m, float s_, float sx, float sy, float sz) {
                           float* o5 = rec + j * 5;
                           o5[0] = m; o5[1] = s_; o5[2] = sx; o5[3] = sy; o5[4] = sz;
@@ -828,9 +844,16 @@ __global__ __launch_bounds__(512, 2) void head_f16_ring_kernel(HeadArgs a) {
 bool head_f16_supported(int c_in, int c_head, int n_joints, int depth, int side) {
     static const int enabled = tuning_knob("METRO_HEAD_FUSED", 1);
     const int pixels = side * side;
-    return enabled && c_head == n_joints * depth && c_head <= hd::TM && c_in % hd::BK == 0 && c_in <= 2048 &&
-           c_in / hd::BK >= hd::STAGES - 1 && pixels % hd::TN == 0 && side >= 2 && depth >= 2;
+    if (!(enabled && c_head == n_joints * depth && c_in % hd::BK == 0 && c_in <= 2048 && c_in / hd::BK >= hd::STAGES - 1 &&
+          pixels % hd::TN == 0 && side >= 2 && depth >= 2))
+        return false;
+    if (c_head <= hd::TM) return true;
+    // wider heads: joint groups of at most 160 channels on the ring kernel (its K loop: an even number of 64-channel steps, >= 6)
+    static const int grouped = tuning_knob("METRO_HEAD_GROUPS", 1);
+    return grouped && depth <= hd::TM && c_in % 128 == 0 && c_in / 64 >= 6 && tuning_knob("METRO_HEAD_RING", 1);
 }
+// joints per group of a head wider than 160 channels (0 = the head is one group)
+static int head_f16_group_joints(int c_head, int depth) { return c_head <= hd::TM ? 0 : hd::TM / depth; }
 // 256-pixel tiles once they still give every CU a tile
 static bool head_f16_big(int n, int side) {
     static const int t256 = tuning_knob("METRO_HEAD_256", 1);
@@ -843,6 +866,7 @@ static int head_f16_variant(int n, int c_in, int c_head, int side) {
     static const int ring = tuning_knob("METRO_HEAD_RING", 1);
     const int pixels = side * side;
     const bool ring_ok = ring && c_in % 128 == 0 && c_in / 64 >= 6;
+    if (c_head > hd::TM) return pixels % 128 == 0 && (long)n * (pixels / 128) >= 256 ? 3 : 4;      // joint groups: ring kernel only
     if (head_f16_big(n, side)) return ring_ok && c_head <= 144 ? 2 : 1;
     if (!ring_ok) return 0;
     if (pixels % 128 == 0 && (long)n * (pixels / 128) >= 256) return 3;
@@ -861,7 +885,8 @@ static int launch_head_ring(const HeadArgs& a, int n, int side, hipStream_t stre
     auto kern = head_f16_ring_kernel<TN, KSPLIT, WROWS>;
     static PerDeviceInt done;
     if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), G::LDS_BYTES, done, "head_f16<ring>")) return st;
-    hipLaunchKernelGGL(kern, dim3(side * side / TN, n), dim3(G::NT), G::LDS_BYTES, stream, a);
+    const int groups = a.JG > 0 ? (a.J + a.JG - 1) / a.JG : 1;
+    hipLaunchKernelGGL(kern, dim3(side * side / TN, n, groups), dim3(G::NT), G::LDS_BYTES, stream, a);
     return launch_status("head_f16<ring>");
 }
 
@@ -873,8 +898,11 @@ int launch_head_f16(const void* x, const void* w, const float* bias, const void*
         return METRO_ERR_UNSUPPORTED;
     }
     const int variant = head_f16_variant(n, c_in, c_head, side);
-    const int wrows = c_head <= 144 ? 144 : 160;
-    if (variant >= 2 ? note_kernel("head_f16<%dx%d,k%d>", wrows, variant == 2 ? 256 : variant == 3 ? 128 : 64, variant == 2 ? 2 : 4)
+    const int jgrp = head_f16_group_joints(c_head, depth);
+    const int wrows = jgrp > 0 ? 160 : c_head <= 144 ? 144 : 160;
+    char grp[16] = "";
+    if (jgrp > 0) snprintf(grp, sizeof(grp), ",g%d", (n_joints + jgrp - 1) / jgrp);
+    if (variant >= 2 ? note_kernel("head_f16<%dx%d,k%d%s>", wrows, variant == 2 ? 256 : variant == 3 ? 128 : 64, variant == 2 ? 2 : 4, grp)
                      : note_kernel(variant == 1 ? "head_f16<160x256>" : "head_f16<160x64>"))
         return METRO_OK;
     HeadArgs a;
@@ -883,6 +911,7 @@ int launch_head_f16(const void* x, const void* w, const float* bias, const void*
     a.partials = partials; a.logits_out = logits_out;
     a.K = c_in; a.C = c_head; a.J = n_joints; a.D = depth; a.side = side; a.pixels = side * side;
     a.slabs = head_f16_records(n, c_in, c_head, side);
+    a.JG = jgrp;
     if (variant == 2) return launch_head_ring<256, 2, 144>(a, n, side, stream);
     if (variant == 3) return wrows == 144 ? launch_head_ring<128, 4, 144>(a, n, side, stream) : launch_head_ring<128, 4, 160>(a, n, side, stream);
     if (variant == 4) return wrows == 144 ? launch_head_ring<64, 4, 144>(a, n, side, stream) : launch_head_ring<64, 4, 160>(a, n, side, stream);

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Per-launch roofline floors of a forward against the measured kernel times (made reproducible).
+
+    python profiles/roofline_floors.py profiles/<tag>_pmc_layers.tsv [arch stride dataset batch] [--mfma-tflops 2500] [--hbm-gbs 6300]
+
+For every launch of the plan:  floor = max(algorithmic FLOPs / MFMA peak, bytes / HBM rate), bytes = the launch's measured
+(2 * FETCH_SIZE + WRITE_SIZE) * 1024 when the table has them (rocprofv3 --pmc; FETCH_SIZE doubled per MI355X_MICROARCH.md), else
+its algorithmic bytes (MetroLayerInfo.algo_*: every tensor the launch touches, once).  Prints the table, the sums and
+Sigma floors / Sigma measured -- with the nominal peaks (2.5 PFLOP/s dense fp16, 6.3 TB/s achievable HBM) and, second line, with
+the ceilings tools/peak_probe.hip measures on this chip (pass them: --mfma-tflops 1650 --hbm-gbs 5800).  No GPU needed: FLOPs and
+algorithmic bytes come from a dry plan."""
+import argparse
+import csv
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('table')
+    ap.add_argument('spec', nargs='*', default=['50', '16', 'h36m', '64'])
+    ap.add_argument('--mfma-tflops', type=float, default=2500.0)
+    ap.add_argument('--hbm-gbs', type=float, default=6300.0)
+    ap.add_argument('--algorithmic-bytes', action='store_true', help='ignore the counters: floors from algorithmic bytes only')
+    a = ap.parse_args()
+    from metro_pose3d_amd import ModelSpec
+    from metro_pose3d_amd.engine import Engine
+    arch, stride, dataset, batch = int(a.spec[0]), int(a.spec[1]), a.spec[2], int(a.spec[3])
+    infos = {li.name.decode(): li for li in Engine(ModelSpec(arch, stride, dataset), None, 'f16', batch).layer_infos()}
+    rows = list(csv.DictReader(open(a.table), delimiter='\t'))
+    tot = dict(us=0.0, floor=0.0, mf=0.0, hb=0.0, flops=0.0, bytes=0.0)
+    print('layer\tus\tGFLOP\tMB\tmfma_floor_us\thbm_floor_us\tfloor_us\tfloor/measured\tbound')
+    for r in rows:
+        name = r['layer']
+        li = infos.get(name) or infos.get(name.replace('_fin', ''))
+        us = float(r['us'])
+        flops = li.flops_per_image * batch if li is not None else 0.0
+        algo = (li.algo_act_bytes_per_image * batch + li.algo_param_bytes) if li is not None else 0.0
+        nbytes = algo
+        if not a.algorithmic_bytes and r.get('FETCH_SIZE') and r.get('WRITE_SIZE'):
+            nbytes = (2.0 * float(r['FETCH_SIZE']) + float(r['WRITE_SIZE'])) * 1024.0
+        mf = flops / (a.mfma_tflops * 1e12) * 1e6
+        hb = nbytes / (a.hbm_gbs * 1e9) * 1e6
+        fl = max(mf, hb)
+        for k, v in (('us', us), ('floor', fl), ('mf', mf), ('hb', hb), ('flops', flops), ('bytes', nbytes)):
+            tot[k] += v
+        print(f'{name}\t{us:.1f}\t{flops / 1e9:.1f}\t{nbytes / 1e6:.1f}\t{mf:.1f}\t{hb:.1f}\t{fl:.1f}\t{fl / us if us else 0:.2f}\t{"mfma" if mf >= hb else "hbm"}')
+    print(f'TOTAL\t{tot["us"]:.1f}\t{tot["flops"] / 1e9:.1f}\t{tot["bytes"] / 1e6:.1f}\t{tot["mf"]:.1f}\t{tot["hb"]:.1f}\t{tot["floor"]:.1f}\t'
+          f'{tot["floor"] / tot["us"]:.3f}\t-')
+    print(f'# peaks: {a.mfma_tflops:.0f} TFLOP/s, {a.hbm_gbs:.0f} GB/s; sum of per-launch floors / sum of measured = {tot["floor"] / tot["us"]:.3f}; '
+          f'whole-forward floors: MFMA {tot["mf"]:.0f} us, HBM {tot["hb"]:.0f} us (the launch set is '
+          f'{"HBM" if tot["hb"] > tot["mf"] else "MFMA"}-bound in aggregate)')
+
+
+if __name__ == '__main__':
+    main()

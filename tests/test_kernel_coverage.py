@@ -38,6 +38,10 @@ CONFIGS = {
     # statistics path: five-joint batches are for depth 8) and 128-pixel tiles with 144 weight rows (17 joints at stride 8)
     'X-rn50-s16-J17-D4-b64': (ModelSpec(50, 16, 'h36m', depth=4), 64),
     'X-rn50-s8-J17-b32': (ModelSpec(50, 8, 'h36m'), 32),
+    # the released `many_*` exports: the 53-joint `merged` head = 424 channels (reference data/datasets.py:142-154, main.py:119-127)
+    # in three joint groups on the ring head (round 5), 64- and 128-pixel tiles
+    'X-rn50-s16-merged53-b64': (ModelSpec(50, 16, 'merged'), 64),
+    'X-rn101-s8-merged53-b32': (ModelSpec(101, 8, 'merged'), 32),
 }
 PERIOD = 4
 
@@ -85,6 +89,8 @@ def test_every_layer_names_its_kernel_without_a_gpu():
     assert ids['C2-rn50-s16-J17-b256']['logits'] == ids['C5-rn50-s4-J17-b16']['logits'] == 'head_f16<144x256,k2>'
     assert ids['C3-rn50-s16-J19-b256']['logits'] == 'head_f16<160x256>'
     assert ids['X-rn50-s16-J17-D4-b64']['logits'] == 'head_f16<144x64,k4>' and ids['X-rn50-s8-J17-b32']['logits'] == 'head_f16<144x128,k4>'
+    assert ids['X-rn50-s16-merged53-b64']['logits'] == 'head_f16<160x64,k4,g3>' and ids['X-rn101-s8-merged53-b32']['logits'] == 'head_f16<160x128,k4,g3>'
+    assert ids['X-rn50-s16-merged53-b64']['softargmax'] == 'softargmax_finalize<acc32>'
     assert ids['C2-rn50-s16-J17-b64']['softargmax'] == 'softargmax_finalize<acc32>'
     # parity modes name their kernels too
     e64 = Engine(ModelSpec(50, 16, 'h36m'), None, 'f64', max_batch=2)
