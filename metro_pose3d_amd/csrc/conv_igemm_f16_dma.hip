@@ -715,7 +715,7 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
         return launch_conv_pws(d, in_, w_, bias, res_, out, stream);
     {
         const int mode = (fuse2 != nullptr && fuse2->w2 != nullptr) ? 2 : (split != nullptr && split->split > 0) ? 1 : 0;
-        if (conv_pw64_supported(d, mode) && (mode != 1 || (split->split == 256 && split->c_out2 == 64 && split->relu2 == 1)) &&
+        if (conv_pw64_supported(d, mode) && (mode != 1 || (split->relu2 == 1 && ((split->split == 256 && split->c_out2 == 64) || (split->split == 512 && split->c_out2 == 128)))) &&
             (mode != 2 || fuse2->c2 == (d.c_in == 128 ? 128 : 64)))
             return launch_conv_pw64(d, in_, w_, bias, ps_, pb_, res_, out, stream, split, fuse2);
     }

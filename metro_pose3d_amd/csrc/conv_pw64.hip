@@ -39,6 +39,7 @@
 //                  residual stream the conv3 launch just wrote) are gone.
 // Arithmetic is that of the tiled kernel: fp32 accumulate, fp16(conv + bias), then the fp16 shortcut add.
 #include <cstdlib>
+#include <type_traits>
 
 #include "metro_common.h"
 
@@ -114,7 +115,8 @@ struct Lay {
 };
 template <int K, int WM, bool RES, int MODE2, bool PSC = false, int CB = 256, bool REB = false>
 constexpr int lds_bytes() {
-    return Lay<K, WM, CB>::RES_OFF + (RES ? 2 * Lay<K, WM, CB>::RES_BYTES : PSC ? (REB ? 4 : 2) * Lay<K, WM, CB>::X_BYTES : 0);
+    return Lay<K, WM, CB>::RES_OFF + (RES ? 2 * Lay<K, WM, CB>::RES_BYTES : PSC ? (REB ? 4 : 2) * Lay<K, WM, CB>::X_BYTES
+                                      : (MODE2 == 1 && K > 64) ? Lay<K, WM, CB>::C2 * (2 * K + 16) + Lay<K, WM, CB>::TN * (2 * Lay<K, WM, CB>::C2 + 16) : 0);
 }
 }  // namespace pw
 
@@ -142,6 +144,23 @@ __device__ __forceinline__ void pw_wait_vm_plus(int extra) {
         else pw_wait_vm_plus<BASE, MAXX - 1>(extra);
     }
 }
+// s_waitcnt lgkmcnt(n), n a compile-time value after unrolling, tied to the register(s) the wait is for
+__device__ __forceinline__ void pw_wait_lgkm(half8_t& r, int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(r)); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r)); break;
+        default: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(r)); break;
+    }
+}
+__device__ __forceinline__ void pw_wait_lgkm2(half8_t& r, half8_t& r2, int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r), "+v"(r2)); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(r), "+v"(r2)); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(r), "+v"(r2)); break;
+        default: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(r), "+v"(r2)); break;
+    }
+}
 __device__ __forceinline__ void pw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -151,8 +170,11 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     using namespace pw;
     using L = Lay<K, WM, CB>;
     static_assert((WM == 4 && K <= 128) || (WM == 8 && K <= 512), "weights must fit the register file as MFMA fragments");
-    static_assert(CB == 256 || (CB == 512 && K == 128 && WM == 8 && RES && !PRO && !RSUB), "512-channel blocks: conv3 of block2");
-    static_assert(MODE2 == 0 || (K == 64 && WM == 4) || (MODE2 == 2 && CB == 512), "second outputs: block1 shapes, or conv3 + next conv1 of block2");
+    static_assert(CB == 256 || (CB == 512 && K == 128 && WM == 8 && RES && !PRO && !RSUB) ||
+                      (CB == 512 && K == 256 && WM == 8 && !RES && PRO && MODE2 == 1),
+                  "512-channel blocks: conv3 of block2, or block2's projection shortcut + conv1 pair");
+    static_assert(MODE2 == 0 || (K == 64 && WM == 4) || (MODE2 == 2 && CB == 512) || (MODE2 == 1 && CB == 512 && K == 256),
+                  "second outputs: block1 shapes, conv3 + next conv1 of block2, or block2's pair");
     static_assert(!PSC || (MODE2 == 2 && !PRO && !RES), "in-launch projection shortcut: conv3 + next conv1 of block1/unit_1");
     static_assert(!REB || PSC, "rebuilt residual: on top of the in-launch projection shortcut");
     static_assert(OUTM == 0 || (MODE2 == 2 && PSC), "outputs kept on chip: the conv3 + next conv1 launches of block1");
@@ -194,11 +216,19 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
 
     // ---- launch-resident operands ------------------------------------------------------------
     half8_t wf[NI][KK];
+    constexpr bool W_STAGED = K >= 128 && pw::lds_bytes<K, WM, RES, MODE2, PSC, CB, REB>() >= NW * W_STAGE_BYTES;   // through LDS (metro_common.h)
+    if constexpr (W_STAGED) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i)
+            load_w_frags_staged<K>(a.w + (size_t)((wm * NI + i) * 32) * K, wf[i], smem + wave * W_STAGE_BYTES, lane);
+        __syncthreads();                                     // the scratch overlays the tile buffers and the parameter block
+    } else {
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
-            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)((wm * NI + i) * 32 + frag_row) * K + kk * 16 + frag_half * 8);
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+                wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)((wm * NI + i) * 32 + frag_row) * K + kk * 16 + frag_half * 8);
+    }
     half8_t wsf[NI][KK];                                     // PSC: the projection shortcut's weights, same fragment layout
     if constexpr (PSC) {
 #pragma unroll
@@ -215,14 +245,31 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
             for (int kk = 0; kk < KK; ++kk)
                 wbf[i][kk] = *reinterpret_cast<const half8_t*>(a.w_b + (size_t)((wm * NI + i) * 32 + frag_row) * K + kk * 16 + frag_half * 8);
     }
-    half8_t w2f[4];
-    if constexpr (MODE2 == 1) {
+    // MODE2 = 1: conv1's rows [C2][K] next to the shortcut's; waves 0-3 own one 32-row tile each (K = 64: 2 row tiles x 2 pixel
+    // tiles; K = 256, CB = 512: 4 row tiles x the one pixel tile -- waves w and w + 4 share a SIMD, so every SIMD issues 3 + 2 MFMAs
+    // per k step)
+    // K = 256: 128 (W) + 64 (W2) fragment registers next to 48 accumulators do not fit 256 VGPRs (80 spilled): there W2 lives in LDS,
+    // rows padded to 2 K + 16 bytes (conflict-free ds_read_b128 of 32 rows), one more fragment read per k step for waves 0-3
+    constexpr bool W2_LDS = MODE2 == 1 && K > 64;
+    constexpr bool PREPASS = PRO && W2_LDS;
+    constexpr int W2_ROW = 2 * K + 16;
+    constexpr int W2_OFF = RES_OFF;                          // (MODE2 = 1 has no shortcut rows: !RES)
+    constexpr int O2_ROW = 2 * C2 + 16, O2_OFF = W2_OFF + C2 * W2_ROW;   // ... and conv1's output tile [TN][C2] goes out in full rows too
+    half8_t w2f[MODE2 == 1 && !W2_LDS ? KK : 1];
+    if constexpr (MODE2 == 1 && !W2_LDS) {
         if (wave < 4) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                w2f[kk] = *reinterpret_cast<const half8_t*>(a.w2 + (size_t)(wm * 32 + frag_row) * 64 + kk * 16 + frag_half * 8);
+            for (int kk = 0; kk < KK; ++kk)
+                w2f[kk] = *reinterpret_cast<const half8_t*>(a.w2 + (size_t)(wm * 32 + frag_row) * K + kk * 16 + frag_half * 8);
         }
     }
+    if constexpr (W2_LDS) {
+        for (int c = tid; c < C2 * (K / 8); c += NT) {
+            const int r = c / (K / 8), q = c % (K / 8);
+            *reinterpret_cast<uint4*>(smem + W2_OFF + r * W2_ROW + q * 16) = *reinterpret_cast<const uint4*>(a.w2 + (size_t)r * K + q * 8);
+        }
+    }
+    const char* w2l = smem + W2_OFF + (wm * 32 + frag_row) * W2_ROW + frag_half * 16;
     float* bias_l = reinterpret_cast<float*>(smem + PAR_OFF);
     float* bias2_l = reinterpret_cast<float*>(smem + PAR_OFF + L::BIAS2_OFF);
     half_t* pro_l = reinterpret_cast<half_t*>(smem + PAR_OFF + L::PRO_OFF);
@@ -299,9 +346,9 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     issue_tile(t, 0);
     // stores of one tile per wave (all younger than the next tile's loads): RI row-wise (+4 second-output)
     // second-output stores per tile: MODE2 = 1 four 8-byte stores by waves 0-3; MODE2 = 2 NTW by every wave
-    constexpr int S2 = MODE2 == 2 ? NTW : 4;
+    constexpr int S2 = MODE2 == 2 ? NTW : (MODE2 == 1 && K > 64) ? 1 : 4;
     constexpr int RS = OUTM == 0 ? RI : 0;                   // row-wise stores of `out` every tile issues (OUTM = 2: 0 .. RI, per tile)
-    const bool two = MODE2 == 2 || (MODE2 == 1 && wave < 4);
+    const bool two = MODE2 == 2 || (MODE2 == 1 && (wave < 4 || K > 64));
     bool prev_full = false;
     int prev_sub = 0;                                        // OUTM = 2: sub-sampled row-wise stores the previous tile issued (wave-uniform)
     for (int it = 0;; ++it, t += G) {
@@ -316,6 +363,22 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         if (t + G < a.n_tiles) issue_tile(t + G, buf ^ 1);
         prev_full = m0 + TN <= a.m_total;
 
+        // ---- K = 256 pair: the pre-activation ONCE per element, in place in the landed tile (resnet_v2.py:119: fp16 BN + ReLU), not
+        //      once per fragment read in each of the 8 waves: per k step a wave is left with one fragment read and its MFMAs
+        if constexpr (PREPASS) {
+            static_assert(X_BYTES / 16 == 2 * NT, "two 16-byte chunks of the input tile per thread");
+            const int c8 = lane & 7, prow = (wave & 3) * 8 + (lane >> 3);
+            const half8_t z = {};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sl = (wave >> 2) + 2 * h;
+                half8_t* xp = reinterpret_cast<half8_t*>(smem + X_OFF + buf * X_BYTES + sl * SL_BYTES + prow * 128 + ((c8 ^ pw_swz(prow)) << 4));
+                const half8_t sc = *reinterpret_cast<const half8_t*>(pro_l + sl * 64 + c8 * 8);
+                const half8_t sh = *reinterpret_cast<const half8_t*>(pro_l + K + sl * 64 + c8 * 8);
+                *xp = __builtin_elementwise_max(*xp * sc + sh, z);
+            }
+            pw_barrier();
+        }
         // ---- GEMM 1: [256 x 64] x [64 x 64 pixels] ---------------------------------------------
         floatx16 acc[NI], acc2, accs[NI];
 #pragma unroll
@@ -373,11 +436,48 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
                     xprev[i][q] = hb + xprev[i][q];      // the fp16 Add of the previous unit (resnet_v2.py:138), as its own launch computes it
                 }
         }
+        if constexpr (PREPASS) {
+            // The fragments run DEPTH k steps ahead of their MFMAs through a register ring, reads and waits in inline asm with counted
+            // lgkmcnt (conv_pws.hip: hipcc turns the C++ form into read - wait - MFMA, one exposed LDS round trip per k step and two in
+            // waves 0-3, which also read conv1's A fragment).  The role (with / without conv1 rows) is wave-uniform: two loops.
+            constexpr int DEPTH = 3;
+            unsigned fbase[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                fbase[c] = smem_base + X_OFF + buf * X_BYTES + brow * 128 + (((2 * c + frag_half) ^ pw_swz(brow)) << 4);
+            const unsigned f2base = smem_base + W2_OFF + (wm * 32 + frag_row) * W2_ROW + frag_half * 16;
+            auto gemm = [&](auto has2_c) {
+                constexpr bool HAS2 = decltype(has2_c)::value;
+                constexpr int PER = HAS2 ? 2 : 1;               // LDS reads per k step
+                half8_t fr[DEPTH], f2[HAS2 ? DEPTH : 1];
+#pragma unroll
+                for (int kk = 0; kk < DEPTH; ++kk) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[kk]) : "v"(fbase[kk & 3]), "n"((kk >> 2) * SL_BYTES));
+                    if constexpr (HAS2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f2[kk]) : "v"(f2base), "n"(kk * 32));
+                }
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    constexpr int D1 = DEPTH - 1;
+                    const int younger = (KK - 1 - kk < D1 ? KK - 1 - kk : D1) * PER;     // a constant after unrolling
+                    if constexpr (HAS2) pw_wait_lgkm2(fr[kk % DEPTH], f2[kk % DEPTH], younger);
+                    else pw_wait_lgkm(fr[kk % DEPTH], younger);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][kk], fr[kk % DEPTH], acc[i], 0, 0, 0);
+                    if constexpr (HAS2) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f2[kk % DEPTH], fr[kk % DEPTH], acc2, 0, 0, 0);
+                    if (kk + DEPTH < KK) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[kk % DEPTH]) : "v"(fbase[(kk + DEPTH) & 3]), "n"(((kk + DEPTH) >> 2) * SL_BYTES));
+                        if constexpr (HAS2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f2[kk % DEPTH]) : "v"(f2base), "n"((kk + DEPTH) * 32));
+                    }
+                }
+            };
+            if (wave < 4) gemm(std::true_type{});
+            else gemm(std::false_type{});
+        } else {
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const int chunk = (kk & 3) * 2 + frag_half;
             half8_t bf = *reinterpret_cast<const half8_t*>(xl + (kk >> 2) * SL_BYTES + brow * 128 + ((chunk ^ pw_swz(brow)) << 4));
-            if constexpr (PRO) {
+            if constexpr (PRO && !PREPASS) {
                 const half8_t s = *reinterpret_cast<const half8_t*>(pro_l + kk * 16 + frag_half * 8);
                 const half8_t b = *reinterpret_cast<const half8_t*>(pro_l + K + kk * 16 + frag_half * 8);
                 const half8_t z = {};
@@ -385,8 +485,11 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][kk], bf, acc[i], 0, 0, 0);
-            if constexpr (MODE2 == 1) {
+            if constexpr (MODE2 == 1 && !W2_LDS) {
                 if (wave < 4) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f[kk], bf, acc2, 0, 0, 0);
+            }
+            if constexpr (W2_LDS) {
+                if (wave < 4) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8_t*>(w2l + kk * 32), bf, acc2, 0, 0, 0);
             }
             if constexpr (PSC && !REB) {
                 // projection shortcut on the pre-activated unit input (same pixels, same k step)
@@ -398,6 +501,7 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) accs[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsf[i][kk], bs, accs[i], 0, 0, 0);
             }
+        }
         }
         if constexpr (MODE2 == 1) {
             // conv1 rows: relu(acc + bias2) -> out2[m][64]   (waves 0..3: couts wm*32.., pixels wn*32..)
@@ -411,7 +515,8 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
                         half4_t hv;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) hv[e] = (half_t)fmaxf(acc2[4 * q + e] + bv[e], 0.f);
-                        *reinterpret_cast<half4_t*>(a.out2 + (size_t)m * 64 + co) = hv;
+                        if constexpr (W2_LDS) *reinterpret_cast<half4_t*>(smem + O2_OFF + (wn * 32 + frag_row) * O2_ROW + co * 2) = hv;   // full rows below
+                        else *reinterpret_cast<half4_t*>(a.out2 + (size_t)m * C2 + co) = hv;
                     }
                 }
             }
@@ -484,6 +589,13 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
                 *reinterpret_cast<half8_t*>(ol + prow * OUT_ROW + ch * 16) = p;
             }
         }
+        if constexpr (W2_LDS) {
+            // conv1's rows: TN x C2 / 8 = 512 chunks of 16 bytes, one per thread
+            static_assert(TN * (C2 / 8) == NT, "one 16-byte chunk of the second output per thread");
+            const int prow2 = tid / (C2 / 8), ch2 = tid % (C2 / 8);
+            const uint4 v2 = *reinterpret_cast<const uint4*>(smem + O2_OFF + prow2 * O2_ROW + ch2 * 16);
+            if (m0 + prow2 < a.m_total) store_out16<1>(a.out2 + (size_t)(m0 + prow2) * C2 + ch2 * 8, v2);
+        }
         if constexpr (MODE2 == 2) {
             pw_barrier();
             // ---- GEMM 2: [C2 x CB] x [CB x TN pixels] from the tile: v_mfma_f32_16x16x32_f16, A[i][k] lane (i = lane & 15, k group =
@@ -536,7 +648,13 @@ bool conv_pw64_supported(const MetroConvDesc& d, int mode) {
                          d.res_offset + 2 * (d.w_out - 1) < d.res_w;
     if (d.has_residual && !res_plain && !(mode == 0 && res_sub && d.c_in <= 128)) return false;
     // built combinations: prologue without shortcut (projection shortcut, pair) / shortcut without prologue (conv3)
-    if (mode == 1) return d.c_in == 64 && d.c_out == 320 && d.has_prologue && !d.has_residual;
+    if (mode == 1) {
+        // block1's pair (64 -> 256 + 64) and, round 5, block2's (256 -> 512 + 128: all 640 weight rows register-resident in one block)
+        static const int pair256 = pw_env_int("METRO_PW_PAIR256", 1);
+        // (under the test switch metro_conv_b1_form(1) the 256-channel pair stays on the ring kernel it replaced: same bits, tested)
+        return ((d.c_in == 64 && d.c_out == 320) || (pair256 && !classic_forms_forced() && d.c_in == 256 && d.c_out == 640)) &&
+               d.has_prologue && !d.has_residual;
+    }
     if (mode == 2) {
         static const int next128 = pw_env_int("METRO_PW_NEXT128", 1);
         return ((d.c_in == 64 && d.c_out == 256) || (next128 && d.c_in == 128 && d.c_out == 512 && res_plain)) && !d.has_prologue && d.has_residual;
@@ -589,7 +707,8 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
         set_error("conv_pw64: bad output mode %d (2 = sub-sampled copy: needs the rebuilt residual, out_sub, sub_off 0|1 and the sub-sampled map size)", outm);
         return METRO_ERR_INVALID_ARG;
     }
-    if (!conv_pw64_supported(d, mode) || (mode == 1 && !(split->split == 256 && split->c_out2 == 64 && split->relu2 == 1)) ||
+    if (!conv_pw64_supported(d, mode) || (mode == 1 && !(split->relu2 == 1 && ((d.c_in == 64 && split->split == 256 && split->c_out2 == 64) ||
+                                                                      (d.c_in == 256 && split->split == 512 && split->c_out2 == 128)))) ||
         (mode >= 2 && f2->c2 != (d.c_in == 128 ? 128 : 64))) {
         set_error("conv_pw64: unsupported layer");
         return METRO_ERR_INVALID_ARG;
@@ -610,12 +729,13 @@ int launch_conv_pw64(const MetroConvDesc& d, const void* in, const void* w, cons
     a.in_b = nullptr; a.w_b = nullptr; a.bias_b = nullptr; a.out_sub = nullptr; a.sub_off = 0; a.h_sub = 0; a.w_sub = 0; a.lw_out = 0;
     a.m_total = d.n * d.h_out * d.w_out;
     a.n_tiles = 0;
-    a.c_out = mode == 1 ? 256 : d.c_out;
+    a.c_out = mode == 1 ? split->split : d.c_out;
     a.res_stride = d.res_stride; a.res_off = d.res_offset; a.res_h = d.res_h; a.res_w = d.res_w;
     a.h_out = d.h_out; a.w_out = d.w_out;
     const bool rsub = d.has_residual && d.res_stride == 2;
     if (mode == 1) {
-        a.w2 = a.w + 256 * 64; a.bias2 = bias + 256; a.out2 = static_cast<half_t*>(split->out2);
+        a.w2 = a.w + (size_t)split->split * d.c_in; a.bias2 = bias + split->split; a.out2 = static_cast<half_t*>(split->out2);
+        if (d.c_in == 256) return launch_pw<256, 8, true, false, 1, false, false, 512>(a, stream);
         return launch_pw<64, 4, true, false, 1>(a, stream);
     }
     if (mode >= 2) {

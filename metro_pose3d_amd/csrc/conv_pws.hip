@@ -131,12 +131,13 @@ __global__ __launch_bounds__(pws::NT) void conv_pws_kernel(PwsArgs a) {
     const int co0 = half * CB + wave * 32;                  // this wave's 32 output channels
 
     // ---- launch-resident operands: the wave's weight rows as 32x32x16 A fragments (K / 4 VGPRs), its bias ---------------------
+    // (staged through a wave-private LDS scratch in 256-byte row pieces -- metro_common.h: fetched as 32-byte pieces straight from
+    // global memory these K / 4 registers cost 17 us (K = 512) / 7 us (K = 256) of L2 requests before the first tile)
     half8_t wf[KK];
+    static_assert(L::BIAS_OFF >= NW * W_STAGE_BYTES, "the staging scratch must not reach the bias block");
+    load_w_frags_staged<K>(a.w + (size_t)co0 * K, wf, smem + wave * W_STAGE_BYTES, lane);
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-        wf[kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(co0 + frag_row) * K + kk * 16 + frag_half * 8);
-        asm volatile("" : "+v"(wf[kk]));                    // pinned: never rematerialised inside the tile loop
-    }
+    for (int kk = 0; kk < KK; ++kk) asm volatile("" : "+v"(wf[kk]));      // pinned: never rematerialised inside the tile loop
     float* bias_l = reinterpret_cast<float*>(smem + L::BIAS_OFF);
     if (tid < CB) bias_l[tid] = a.bias[half * CB + tid];
 

@@ -69,6 +69,40 @@ __device__ __forceinline__ void store_out16(void* p, uint4 v) {
     *reinterpret_cast<uint4*>(p) = v;
 }
 
+// ---- launch-resident weight fragments of the persistent (weight-stationary) kernels -------------------------------------------
+// A wave keeps `rows32` x 32 weight rows [.][K] as v_mfma_f32_32x32x16_f16 A fragments: lane (r = lane & 31, h = lane >> 5) holds
+// W[row][16 kk + 8 h .. + 7] for every k step kk.  Loading them straight from global memory asks the L2 for 32 rows x 32 bytes per
+// wave instruction -- and the L2s answer a near-constant REQUEST rate (~120 G requests/s chip-wide, whatever the size):
+// 256 blocks x 8 waves x K/4 instructions x 32 pieces is 2.1 M requests = 16-17 us at K = 512 (8 us at K = 256) before the first
+// MFMA of the launch, measured as the batch-independent part of conv_pws / conv_pw64 (round 5).  Staged form: the wave copies 32
+// rows x 256 bytes per step with 8 loads of 4 x 256 contiguous bytes (8x fewer, 8x larger requests) into a PRIVATE 8.5 KiB LDS
+// scratch (rows padded to 272 bytes: conflict-free 16-byte reads of 32 rows) and reads its fragments back.  No barrier: LDS
+// executes a wave's instructions in order; wave_barrier() only keeps hipcc from moving the reads above the writes.
+constexpr int W_STAGE_ROW = 272;
+constexpr int W_STAGE_BYTES = 32 * W_STAGE_ROW;            // per wave
+template <int K, typename Frag>
+__device__ __forceinline__ void load_w_frags_staged(const _Float16* __restrict__ rows /* the wave's first row */, Frag* wf /* [K / 16] */,
+                                                    char* scratch /* wave-private, W_STAGE_BYTES */, int lane) {
+    static_assert(K % 128 == 0 || K == 64, "whole 256-byte row pieces (K = 64: one 128-byte piece)");
+    constexpr int PIECE = K >= 128 ? 128 : 64;             // channels per staged step
+    constexpr int LPR = PIECE / 8;                         // lanes per row: 16 (or 8)
+    constexpr int RPI = 64 / LPR;                          // rows per load instruction: 4 (or 8)
+    const int lr = lane / LPR, lc = lane % LPR;
+    const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < K / PIECE; ++c) {
+#pragma unroll
+        for (int j = 0; j < 32 / RPI; ++j)
+            *reinterpret_cast<uint4*>(scratch + (j * RPI + lr) * W_STAGE_ROW + lc * 16) =
+                *reinterpret_cast<const uint4*>(rows + (size_t)(j * RPI + lr) * K + c * PIECE + lc * 8);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k8 = 0; k8 < PIECE / 16; ++k8)
+            wf[c * (PIECE / 16) + k8] = *reinterpret_cast<const Frag*>(scratch + fr * W_STAGE_ROW + k8 * 32 + fh * 16);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- per-device one-time kernel setup -----------------------------------------------------------------------
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the occupancy query act on the CURRENT device's copy of a
 // kernel: a process that drives several GPUs (inference.py caches one Engine per device) must do them once per

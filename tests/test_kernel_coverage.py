@@ -276,6 +276,21 @@ def _conv(lib, cuda, li, n, gen, rng, dev, kid, name):
         out2 = torch.full((n, h_out, h_out, li.out2_channels), float('nan'), dtype=torch.float16, device=cuda)
         check(lib.metro_conv_f16_pair(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(out), c1, H.ptr(out2), None),
               'metro_conv_f16_pair')
+        if kid.startswith('conv_pw64<k256'):   # block2's pair in the weight-resident kernel and in the ring kernel it replaced: the same bits
+            torch.cuda.synchronize()
+            mine, mine2 = out.clone(), out2.clone()
+            check(lib.metro_conv_b1_form(1), 'metro_conv_b1_form')
+            try:
+                check(lib.metro_conv_f16_pair(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(out), c1, H.ptr(out2), None),
+                      'metro_conv_f16_pair (ring kernel)')
+                torch.cuda.synchronize()
+            finally:
+                lib.metro_conv_b1_form(0)
+            assert _noted(lib)[-1].startswith('conv_igemm_f16_dma<'), _noted(lib)
+            assert torch.equal(out, mine) and torch.equal(out2, mine2), f'{kid}: differs from {_noted(lib)[-1]}'
+            check(lib.metro_kernel_notes(1), 'metro_kernel_notes')
+            check(lib.metro_conv_f16_pair(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(out), c1, H.ptr(out2), None),
+                  'metro_conv_f16_pair')
     elif nxt:
         c2 = li.out2_channels
         w2 = (rng.standard_normal((c2, c1)) * np.sqrt(2.0 / c1)).astype(np.float16)
