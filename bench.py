@@ -103,7 +103,10 @@ def peak_measured_for(bound: str):
     if 'error' in pk:
         return {'error': pk['error']}
     if bound == 'mfma':
-        return {k: pk[k] for k in ('mfma_f16_random', 'mfma_f16_relu_x_he', 'mfma_f16_zeros') if k in pk} | {'unit': 'TFLOP/s', 'source': pk['source']}
+        # the forward is MFMA-bound in some launches and HBM-bound in others: both measured ceilings travel with its fraction
+        return ({k: pk[k] for k in ('mfma_f16_random', 'mfma_f16_relu_x_he', 'mfma_f16_zeros') if k in pk} | {'unit': 'TFLOP/s'} |
+                {'hbm': {k: pk[k] for k in ('hbm_read_1GiB', 'hbm_copy_1GiB', 'hbm_read_64MiB', 'hbm_copy_64MiB') if k in pk} | {'unit': 'GB/s'},
+                 'source': pk['source']})
     return {k: pk[k] for k in ('hbm_read_1GiB', 'hbm_copy_1GiB', 'hbm_read_64MiB', 'hbm_copy_64MiB') if k in pk} | {'unit': 'GB/s', 'source': pk['source']}
 
 

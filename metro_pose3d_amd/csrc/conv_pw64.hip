@@ -523,12 +523,20 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
         }
         // ---- accumulators (+bias) -> LDS tile [pixel][cout] fp16 -------------------------------
         char* ol = smem + OUT_OFF;
+        // the tile's 4 NI bias reads FIRST, back to back (hipcc's own order is read - wait - convert - write per group of four channels:
+        // 4 NI exposed LDS round trips per tile in every wave); the B fragments are dead by now, their registers hold the bias
+        floatx4 bvv[NI][4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bvv[i][q] = *reinterpret_cast<const floatx4*>(bias_l + (wm * NI + i) * 32 + 8 * q + 4 * frag_half);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int col = (wm * NI + i) * 32 + 8 * q + 4 * frag_half;
-                const floatx4 bv = *reinterpret_cast<const floatx4*>(bias_l + col);
+                const floatx4 bv = bvv[i][q];
                 half4_t hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) hv[e] = (half_t)(acc[i][4 * q + e] + bv[e]);
@@ -556,21 +564,40 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
             img0 = m0 / hw;
             rem0 = m0 - img0 * hw;
         }
+        // OUTM = 0: the RI chunk (and shortcut) reads of the pass back to back, then sums and stores.  A tile that lies inside the
+        // tensor (wave-uniform test; every tile but the last) stores without per-lane guards: a guard is an exec-mask branch per
+        // iteration, and hipcc does not move the next iteration's LDS reads across it (read - wait - add - store, RI times)
+        uint4 vpre[OUTM == 0 ? RI : 1], rpre[OUTM == 0 && RES ? RI : 1];
+        if constexpr (OUTM == 0) {
+#pragma unroll
+            for (int r = 0; r < RI; ++r) {
+                const int idx = tid + r * NT;
+                vpre[r] = *reinterpret_cast<const uint4*>(ol + (idx / CPR) * OUT_ROW + ch * 16);
+                if constexpr (RES) rpre[r] = *reinterpret_cast<const uint4*>(rl + idx * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const bool inside = m0 + TN <= a.m_total;
 #pragma unroll
         for (int r = 0; r < RI; ++r) {
             const int idx = tid + r * NT;
             const int prow = idx / CPR;
             const int m = m0 + prow;
-            uint4 v = *reinterpret_cast<const uint4*>(ol + prow * OUT_ROW + ch * 16);
+            uint4 v;
+            if constexpr (OUTM == 0) v = vpre[r];
+            else v = *reinterpret_cast<const uint4*>(ol + prow * OUT_ROW + ch * 16);
             if constexpr (RES) {
-                const uint4 rv = *reinterpret_cast<const uint4*>(rl + idx * 16);
+                uint4 rv;
+                if constexpr (OUTM == 0) rv = rpre[r];
+                else rv = *reinterpret_cast<const uint4*>(rl + idx * 16);
                 half2_t* x = reinterpret_cast<half2_t*>(&v);
                 const half2_t* rr = reinterpret_cast<const half2_t*>(&rv);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = x[e] + rr[e];       // fp16 Add, like the reference graph
             }
             if constexpr (OUTM == 0) {
-                if (m < a.m_total) store_out16<1>(a.out + (size_t)m * ldo + ch * 8, v);
+                if (inside) store_out16<1>(a.out + (size_t)m * ldo + ch * 8, v);
+                else if (m < a.m_total) store_out16<1>(a.out + (size_t)m * ldo + ch * 8, v);
             }
             if constexpr (OUTM == 2) {
                 const int hr = ((rem0 + 16 * r) >> a.lw_out) - a.sub_off;         // wave-uniform: map row of this instruction's pixels
