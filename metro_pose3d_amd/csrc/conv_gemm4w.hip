@@ -2,7 +2,7 @@
 //
 // experimental/conv_gemm8p.hip (round 2, no longer dispatched) gives each of its eight waves a 128 x 64 tile: 24 ds_read_b128 per 32 MFMAs, and at batch 256 hipBLASLt's
 // 256^2 kernel (four waves, 128 x 128 wave tiles: 32 reads per 64 MFMAs = two thirds of the LDS fragment bytes per MFMA) was
-// 22-28 % ahead on every deep-K shape ("the ROCm libraries on the same shapes").  This is that geometry:
+// 22-28 % ahead on every deep-K shape (NOTES_dead_ends.md, "the ROCm libraries on the same shapes").  This is that geometry:
 //   * one wave per SIMD, 256 fp32 accumulator registers (4 x 4 tiles of 32 x 32) + two fragment sets + one staged K tile:
 //     the whole 512-register file of the SIMD belongs to the wave;
 //   * operands are REGISTER staged: global_load_dwordx4 -> VGPR -> ds_write_b128 (XOR-swizzled rows as everywhere in this
@@ -277,6 +277,23 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     constexpr int EPI_ITERS = TN * CPRO / NT;          // 32
     const bool res_same = a.res_stride == 1 && a.res_offset == 0 && a.res_h == a.h_out && a.res_w == a.w_out;
     const int hw_out = a.h_out * a.w_out;
+    // no shortcut to add (every layer this kernel is dispatched for) and a whole 256-channel tile: the chunk reads of eight
+    // iterations back to back, then eight full-line stores.  The general loop below carries a per-lane guard and the shortcut
+    // branches in every iteration -- hipcc emits read - wait - store 32 times in a row (~2.5 us per 256 x 256 tile).
+    if (residual == nullptr && o_n0 + TM <= o_c) {
+        const int ch = tid & (CPRO - 1), pr0 = tid / CPRO;         // NT % CPRO == 0: a lane keeps its chunk column
+#pragma unroll
+        for (int it0 = 0; it0 < EPI_ITERS; it0 += 8) {
+            uint4 vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = *reinterpret_cast<const uint4*>(smem + (pr0 + (it0 + u) * (NT / CPRO)) * OUT_ROW_BYTES + ch * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                store_out16<2>(o_ptr + (size_t)(m0 + pr0 + (it0 + u) * (NT / CPRO)) * o_c + o_n0 + ch * 8, vv[u]);
+        }
+        return;
+    }
 #pragma unroll 4
     for (int it = 0; it < EPI_ITERS; ++it) {
         const int idx = tid + it * NT;

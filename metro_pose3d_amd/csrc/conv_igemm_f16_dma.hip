@@ -535,6 +535,43 @@ __device__ __forceinline__ void conv_dma_body(
     __syncthreads();
     // 2) row-wise: 16 bytes per lane, (+ prefetched residual), full-line stores
     half_t* outh = reinterpret_cast<half_t*>(o_ptr);
+    // A tile that lies inside the tensor (block-uniform test: every tile of the production shapes but ragged last ones) takes the
+    // guard-free form: the chunk reads of up to eight iterations back to back, then the sums and stores.  The guarded loop below
+    // is an exec-mask branch per iteration, across which hipcc moves no LDS read: read - wait - store, EPI_ITERS times in a row
+    // (8-16 exposed LDS round trips per tile: ~1.2 us of a 15 us one-tile-per-CU launch at batch 64).
+    constexpr int EPI_G = EPI_ITERS % 8 == 0 ? 8 : EPI_ITERS % 4 == 0 ? 4 : EPI_ITERS % 2 == 0 ? 2 : 1;
+    const bool interior = m0 + Cfg::TN <= a.m_total && o_n0 + Cfg::TM <= o_c;
+    if (interior) {
+#pragma unroll
+        for (int it0 = 0; it0 < EPI_ITERS; it0 += EPI_G) {
+            uint4 vv[EPI_G];
+#pragma unroll
+            for (int u = 0; u < EPI_G; ++u) {
+                const int idx = tid + (it0 + u) * Cfg::NT;
+                const int prow = idx / CPRO;
+                vv[u] = *reinterpret_cast<const uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + (idx - prow * CPRO) * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < EPI_G; ++u) {
+                const int idx = tid + (it0 + u) * Cfg::NT;
+                const int prow = idx / CPRO;
+                const int ch = idx - prow * CPRO;
+                uint4 v = vv[u];
+                if (residual != nullptr) {
+                    half2_t* x = reinterpret_cast<half2_t*>(&v);
+                    const half2_t* r = reinterpret_cast<const half2_t*>(&rres[it0 + u]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = x[e] + r[e];    // fp16 Add, like the reference graph
+                }
+#ifdef METRO_DBG_SKIP_STORE
+                if (a.m_total < 0)
+#endif
+                store_out16<2>(outh + (size_t)(m0 + prow) * o_c + o_n0 + ch * 8, v);
+                if constexpr (FUSE2) *reinterpret_cast<uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16) = v;
+            }
+        }
+    } else
 #pragma unroll
     for (int it = 0; it < EPI_ITERS; ++it) {
         const int idx = tid + it * Cfg::NT;

@@ -1,6 +1,6 @@
 // 1x1 convolution as a 256 x 256 x 64 GEMM with FOUR waves of 128 x 128 and BOTH operands by LDS-DMA (gfx950): the deep-K 1x1 layers.
 //
-// Where the two older forms of this GEMM stand ("the ROCm libraries on the same shapes"): conv_gemm8p.hip (eight waves
+// Where the two older forms of this GEMM stand (NOTES_dead_ends.md, "the ROCm libraries on the same shapes"): conv_gemm8p.hip (eight waves
 // of 128 x 64, LDS-DMA) reads 24 fragments per 32 MFMAs and is bound by the LDS; conv_gemm4w.hip (four waves of 128 x 128: 32 reads
 // per 64 MFMAs) stages through registers, and its ds_write_b128s (13 cycles each on the VGPR -> LDS path) + their waits sit in the
 // one wave per SIMD that also issues the MFMAs.  The library's own best kernel on these shapes (hipBLASLt MT256x256x64, four waves,

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(hd2::NT) void head_f16_kernel256(HeadArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 4: the head in 128-byte row pieces with K-split wave tiles, for every tile width (head_f16_ring_kernel<TN, KSPLIT, WROWS>).
-// What the kernels above are bound by: (1) 32-channel K steps are 64-byte row pieces -- the L2s answer a
+// What the kernels above are bound by (NOTES_dead_ends.md, rounds 3-4): (1) 32-channel K steps are 64-byte row pieces -- the L2s answer a
 // roughly constant REQUEST rate, half-line requests halve the bytes (8.7 against 13.8 TB/s); (2) a wave tile of 160 channels x 32
 // pixels over the whole K reads 7 KB of fragments per 5 MFMAs: more LDS time than MFMA time; (3) a barrier per step with dependent
 // fragment reads behind it; (4) a serial statistics phase (a dependent LDS read per depth, a dependent shuffle per fold step).  Here:

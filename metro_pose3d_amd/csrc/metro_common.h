@@ -72,7 +72,7 @@ __device__ __forceinline__ void store_out16(void* p, uint4 v) {
 // ---- launch-resident weight fragments of the persistent (weight-stationary) kernels -------------------------------------------
 // A wave keeps `rows32` x 32 weight rows [.][K] as v_mfma_f32_32x32x16_f16 A fragments: lane (r = lane & 31, h = lane >> 5) holds
 // W[row][16 kk + 8 h .. + 7] for every k step kk.  Loading them straight from global memory asks the L2 for 32 rows x 32 bytes per
-// wave instruction -- and the L2s answer a near-constant REQUEST rate (DESIGN.md: ~120 G requests/s chip-wide, whatever the size):
+// wave instruction -- and the L2s answer a near-constant REQUEST rate (DESIGN.md section 5: ~120 G requests/s chip-wide, whatever the size):
 // 256 blocks x 8 waves x K/4 instructions x 32 pieces is 2.1 M requests = 16-17 us at K = 512 (8 us at K = 256) before the first
 // MFMA of the launch, measured as the batch-independent part of conv_pws / conv_pw64 (round 5).  Staged form: the wave copies 32
 // rows x 256 bytes per step with 8 loads of 4 x 256 contiguous bytes (8x fewer, 8x larger requests) into a PRIVATE 8.5 KiB LDS
