@@ -38,6 +38,8 @@ constexpr int NPROD = 8, NCONS = 4, NT = 64 * (NPROD + NCONS), TN = 64, K = 64, 
 constexpr int X_BYTES = TN * 128;              // one input tile: 64 pixels x 64 fp16, 128-byte rows, chunk-swizzled
 constexpr int OUT_ROW = CB * 2 + 16;           // padded rows of a [pixel][channel] tile
 constexpr int OUT_BYTES = TN * OUT_ROW;
+constexpr int W1S_ROW = CB * 2 + 16;           // staged W1 rows (prologue only, in the second output tile)
+static_assert(48 * W1S_ROW <= OUT_BYTES, "W1's stage must fit the second output tile");
 template <bool REB>
 struct Lay {
     static constexpr int NIN = REB ? 3 : 2;                    // input tiles per pixel tile: t2 | x0 | (t2 of the previous unit)
@@ -142,6 +144,13 @@ __global__ __launch_bounds__(b1::NT) void conv_b1_chain_kernel(B1Args a) {
             *reinterpret_cast<uint4*>(smem + L::W1T_OFF + tid * 16) =
                 *reinterpret_cast<const uint4*>(a.w2 + (size_t)(48 + (ln & 15)) * CB + ks * 32 + (ln >> 4) * 8);
         }
+        // W1 rows 0 .. 47 (the consumers' register-resident part) take the same road as every weight-stationary kernel's fragments
+        // since round 5 (metro_common.h: load_w_frags_staged): fetched ONCE per block in whole 512-byte rows into the second output
+        // tile's LDS (idle until the producers' tile 1; rows padded to 528 bytes) instead of by each of the four consumer waves in
+        // 64-byte pieces -- 192 requests per block instead of 1 536 (the L2s answer a near-constant request rate: DESIGN.md section 5)
+        for (int c = tid; c < 48 * 32; c += NT)
+            *reinterpret_cast<uint4*>(smem + L::OUT_OFF + OUT_BYTES + (c >> 5) * W1S_ROW + (c & 31) * 16) =
+                *reinterpret_cast<const uint4*>(a.w2 + (size_t)(c >> 5) * CB + (c & 31) * 8);
         if (tid < 64) {
             f[L::B2 / 4 + tid] = a.bias2[tid];
             reinterpret_cast<half_t*>(par + L::PRO)[tid] = a.pro_scale[tid];
@@ -154,13 +163,14 @@ __global__ __launch_bounds__(b1::NT) void conv_b1_chain_kernel(B1Args a) {
     // consumers' W1 never share a register budget.  Every wave executes 1 + (T + 1) barriers.
     if (producer) {
         // W3 | Wsc | (W3 of the previous unit) as 32x32x16 A fragments of this wave's 32 output channels
+        // (staged through a wave-private LDS scratch in whole 128-byte rows: 8 requests per instruction instead of 32)
         half8_t wf[4], wsf[4], wbf[4];
+        static_assert(NPROD * W_STAGE_BYTES <= L::OUT_OFF + OUT_BYTES, "the staging scratch must stay below the second output tile (W1's stage)");
+        load_w_frags_staged<K>(a.w + (size_t)wave * 32 * K, wf, smem + wave * W_STAGE_BYTES, lane);
+        load_w_frags_staged<K>(a.w_sc + (size_t)wave * 32 * K, wsf, smem + wave * W_STAGE_BYTES, lane);
+        if constexpr (REB) load_w_frags_staged<K>(a.w_b + (size_t)wave * 32 * K, wbf, smem + wave * W_STAGE_BYTES, lane);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const size_t o = (size_t)(wave * 32 + frag_row) * K + kk * 16 + frag_half * 8;
-            wf[kk] = *reinterpret_cast<const half8_t*>(a.w + o);
-            wsf[kk] = *reinterpret_cast<const half8_t*>(a.w_sc + o);
-            if constexpr (REB) wbf[kk] = *reinterpret_cast<const half8_t*>(a.w_b + o);
             // pin: an empty asm makes the fragment the result of an instruction that cannot be re-executed -- under register pressure
             // hipcc otherwise REMATERIALISES such loads inside the tile loop (24 global loads per tile in the first build)
             asm volatile("" : "+v"(wf[kk]), "+v"(wsf[kk]));
@@ -290,14 +300,15 @@ __global__ __launch_bounds__(b1::NT) void conv_b1_chain_kernel(B1Args a) {
     } else {
         // W1 of the next unit over K = 256 as 16x16x32 A fragments: rows 0 .. 47 in registers, rows 48 .. 63 in LDS (above)
         half8_t w2r[3][8];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // parameters and W1's stage in LDS
+        // (read before this wave's first loop barrier; the producers overwrite the stage behind their second one)
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                w2r[mt][ks] = *reinterpret_cast<const half8_t*>(a.w2 + (size_t)(mt * 16 + (lane & 15)) * CB + ks * 32 + (lane >> 4) * 8);
+                w2r[mt][ks] = *reinterpret_cast<const half8_t*>(smem + L::OUT_OFF + OUT_BYTES + (mt * 16 + (lane & 15)) * W1S_ROW + ks * 64 + (lane >> 4) * 16);
                 asm volatile("" : "+v"(w2r[mt][ks]));        // pinned in registers (see the producers' weights)
             }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // parameters in LDS
         const int wb = wave - NPROD;
         const int px = wb * 16 + (lane & 15), kg = lane >> 4;
         for (int j = 0; j <= T; ++j) {

@@ -217,10 +217,16 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     // ---- launch-resident operands ------------------------------------------------------------
     half8_t wf[NI][KK];
     constexpr bool W_STAGED = K >= 128 && pw::lds_bytes<K, WM, RES, MODE2, PSC, CB, REB>() >= NW * W_STAGE_BYTES;   // through LDS (metro_common.h)
+    constexpr int RG = C2 / 16;                              // MODE2 = 2: row groups of W2: 4 (CB 256) or 8 (CB 512)
+    constexpr int NTW = TN / 16 / (NW / RG);                 // 16-pixel tiles per wave: 2
+    constexpr int KS2 = CB / 32;                             // k steps of 32
+    half8_t w2r[MODE2 == 2 ? KS2 : 1];                       // W2 [C2][CB] as 16x16x32 A fragments (see below)
     if constexpr (W_STAGED) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
             load_w_frags_staged<K>(a.w + (size_t)((wm * NI + i) * 32) * K, wf[i], smem + wave * W_STAGE_BYTES, lane);
+        // W2's fragments take the same road (256-byte row pieces, not 64-byte ones: 4x fewer L2 requests)
+        if constexpr (MODE2 == 2) load_w_frags16_staged<CB>(a.w2 + (size_t)((wave % RG) * 16) * CB, w2r, smem + wave * W_STAGE_BYTES, lane);
         __syncthreads();                                     // the scratch overlays the tile buffers and the parameter block
     } else {
 #pragma unroll
@@ -286,16 +292,14 @@ __global__ __launch_bounds__(pw::NT) void conv_pw64_kernel(Pw64Args a) {
     // MODE2 = 2: W2 [C2][CB] (the next unit's conv1) in registers as 16x16x32 A fragments: wave w owns output rows 16 (w % RG) ..
     // + 15 over the whole K = CB, for the pixels of its pixel group w / RG (round 3: the 64 -> 256 kernels ran this GEMM on four
     // of their eight waves from an LDS image of W2)
-    constexpr int RG = C2 / 16;                              // row groups: 4 (CB 256) or 8 (CB 512)
-    constexpr int NTW = TN / 16 / (NW / RG);                 // 16-pixel tiles per wave: 2
-    constexpr int KS2 = CB / 32;                             // k steps of 32
-    half8_t w2r[MODE2 == 2 ? KS2 : 1];
     if constexpr (MODE2 == 2) {
         sc2 = *reinterpret_cast<const half8_t*>(a.scale2 + ch * 8);
         sh2 = *reinterpret_cast<const half8_t*>(a.shift2 + ch * 8);
+        if constexpr (!W_STAGED) {
 #pragma unroll
-        for (int ks = 0; ks < KS2; ++ks)
-            w2r[ks] = *reinterpret_cast<const half8_t*>(a.w2 + (size_t)((wave % RG) * 16 + (lane & 15)) * CB + ks * 32 + (lane >> 4) * 8);
+            for (int ks = 0; ks < KS2; ++ks)
+                w2r[ks] = *reinterpret_cast<const half8_t*>(a.w2 + (size_t)((wave % RG) * 16 + (lane & 15)) * CB + ks * 32 + (lane >> 4) * 8);
+        }
     }
 
     // ---- per-lane DMA coordinates ------------------------------------------------------------

@@ -103,6 +103,26 @@ __device__ __forceinline__ void load_w_frags_staged(const _Float16* __restrict__
     }
 }
 
+// The same for v_mfma_f32_16x16x32_f16 A fragments: 16 weight rows [.][K], lane (r = lane & 15, g = lane >> 4) holds
+// W[row][32 ks + 8 g .. + 7] for every k step ks (K / 32 registers of 16 bytes).  Staged 128 channels (256-byte row pieces) at a time.
+template <int K, typename Frag>
+__device__ __forceinline__ void load_w_frags16_staged(const _Float16* __restrict__ rows, Frag* wf /* [K / 32] */, char* scratch, int lane) {
+    static_assert(K % 128 == 0, "whole 256-byte row pieces");
+    const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+    for (int c = 0; c < K / 128; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<uint4*>(scratch + (j * 4 + lr) * W_STAGE_ROW + lc * 16) =
+                *reinterpret_cast<const uint4*>(rows + (size_t)(j * 4 + lr) * K + c * 128 + lc * 8);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+            wf[c * 4 + k4] = *reinterpret_cast<const Frag*>(scratch + (lane & 15) * W_STAGE_ROW + k4 * 64 + (lane >> 4) * 16);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- per-device one-time kernel setup -----------------------------------------------------------------------
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the occupancy query act on the CURRENT device's copy of a
 // kernel: a process that drives several GPUs (inference.py caches one Engine per device) must do them once per

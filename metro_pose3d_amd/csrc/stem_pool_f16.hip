@@ -460,13 +460,24 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
 #pragma unroll
     for (int r = 0; r < 11; ++r) issue_row(plo + r - 3, r);
     // launch-resident weights as B fragments: both 32-channel tiles, 14 k-steps; the per-lane bias of its two channels
+    // Round 5: the 28 KiB weight matrix is fetched ONCE per block in whole 448-byte rows into the (not yet zeroed) window area and
+    // every wave reads its 28 fragments from there -- fetched in fragment order straight from global memory it is 32 rows x 32
+    // bytes per wave instruction: 3 584 L2 requests per block, 7.3 M per launch at batch 256 against 2.6 M for the crops and the
+    // pooled output together (the L2s answer a near-constant request rate: DESIGN.md section 5).  Rows padded to 464 bytes:
+    // conflict-free 16-byte reads of 32 rows.
+    constexpr int WST_ROW = 224 * 2 + 16;
+    static_assert(64 * WST_ROW <= NWR * WROW, "the staged weights must fit the window area");
+    for (int c = tid; c < 64 * 28; c += NT)
+        *reinterpret_cast<uint4*>(smem + WIN_OFF + (c / 28) * WST_ROW + (c % 28) * 16) = *reinterpret_cast<const uint4*>(a.w + (size_t)(c / 28) * 224 + (c % 28) * 8);
+    float bias_l[2] = {a.bias[n], a.bias[32 + n]};
+    __syncthreads();
     half8_t wf[2][KK];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
-            wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)(i * 32 + n) * 224 + kk * 16 + hh * 8);
-    float bias_l[2] = {a.bias[n], a.bias[32 + n]};
+            wf[i][kk] = *reinterpret_cast<const half8_t*>(smem + WIN_OFF + (i * 32 + n) * WST_ROW + kk * 32 + hh * 16);
+    __syncthreads();                               // every wave has its fragments: the window area may be zeroed
     // zero window (the borders stay zero: the cast only writes the 256 interior pixels of a row); the -inf row of the edge table
     for (int i = tid; i < NWR * WROW / 16; i += NT) reinterpret_cast<uint4*>(smem + WIN_OFF)[i] = make_uint4(0, 0, 0, 0);
     if (tid < 32) reinterpret_cast<unsigned*>(smem + EDGE_OFF + NW * 128)[tid] = 0xfc00fc00u;
