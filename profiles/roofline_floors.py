@@ -21,13 +21,21 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('table')
-    ap.add_argument('spec', nargs='*', default=['50', '16', 'h36m', '64'])
+    ap.add_argument('spec', nargs='*', default=None,
+                    help='arch stride dataset batch of the table (default: read off its name as profiles/collect.sh writes them: '
+                         '<tag>_pmc_layers.tsv = RN50-s16 h36m batch 64, _b256_ = batch 256, _c3_ / _c4_ / _c5_ = the shards)')
     ap.add_argument('--mfma-tflops', type=float, default=2500.0)
     ap.add_argument('--hbm-gbs', type=float, default=6300.0)
     ap.add_argument('--algorithmic-bytes', action='store_true', help='ignore the counters: floors from algorithmic bytes only')
     a = ap.parse_args()
     from metro_pose3d_amd import ModelSpec
     from metro_pose3d_amd.engine import Engine
+    if not a.spec:        # FLOPs scale with the batch: a wrong default silently quarters the MFMA floors of a batch-256 table
+        name = os.path.basename(a.table)
+        a.spec = (['50', '16', 'h36m', '256'] if '_b256_' in name else ['50', '16', 'many19', '64'] if '_c3_' in name else
+                  ['101', '8', 'many19', '32'] if '_c4_' in name else ['50', '4', 'h36m', '16'] if '_c5_' in name else ['50', '16', 'h36m', '64'])
+    if len(a.spec) != 4:
+        ap.error('spec = arch stride dataset batch')
     arch, stride, dataset, batch = int(a.spec[0]), int(a.spec[1]), a.spec[2], int(a.spec[3])
     infos = {li.name.decode(): li for li in Engine(ModelSpec(arch, stride, dataset), None, 'f16', batch).layer_infos()}
     rows = list(csv.DictReader(open(a.table), delimiter='\t'))
