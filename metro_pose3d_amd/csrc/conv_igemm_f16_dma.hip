@@ -817,6 +817,11 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
     static const int big = env_int("METRO_DMA_BIG", 2);
     if (big && d.c_out % 256 == 0 && blocks256 / 2 >= 256) { METRO_DMA(Dma256x256s4k32); }
     if (blocks256 >= 256) { METRO_DMA(Dma128x256s3); }
+    // deep-K layers whose 128 x 128 tiles leave CUs idle (block2/unit_4's strided 3x3 at batch 64: 128 tiles on 256 CUs): 64-cout
+    // tiles double the blocks (same pixel gather per block, half the weight rows and MFMAs per K step); same bits
+    static const int half_tiles = env_int("METRO_DMA_HALF_TILES", 1);
+    const long blocks128 = (long)tiles128 * ((a.m_total + 127) / 128);
+    if (half_tiles && d.c_out % 64 == 0 && blocks128 >= 64 && blocks128 < 224 && a.split == 0) { METRO_DMA(Dma64x128s3); }
     METRO_DMA(Dma128x128s4);
 #undef METRO_DMA
 }
