@@ -274,7 +274,8 @@ int  metro_conv_f16_next_rebuild(const MetroConvDesc* d, const void* d_in, const
  * the producer / consumer kernel of conv_b1.hip ("conv_b1_chain<...>"); 1 = run the classic single-role kernel of conv_pw64.hip
  * instead (what metro_forward_upto stopping at such a layer runs): two independent forms that must give the same bits.
  * It also switches metro_conv_f16 between conv_pws.hip's skewed kernel (default; conv3 + shortcut of blocks 3-4) and
- * conv_pw64.hip's lock-step one (1): again the same bits. */
+ * conv_pw64.hip's lock-step one (1), and metro_conv_f16_pair on block2's shapes (256 -> 512 + 128) between the weight-resident
+ * kernel conv_pw64<k256,wm8,cb512,pro,pair> (default, round 5) and the ring kernel it replaced (1): again the same bits. */
 int  metro_conv_b1_form(int32_t classic);
 /* The same contract as metro_conv_f16 / metro_conv_f16_pair on the 256 x 256 x 64 GEMM kernel with four waves of 128 x 128
  * (conv_gemm4w.hip: register-staged operands, one barrier per K tile), which metro_forward picks for the pre-activated deep-K

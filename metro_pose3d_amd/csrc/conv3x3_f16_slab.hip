@@ -37,10 +37,6 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page_slab[4];
 typedef __attribute__((address_space(3))) void lds_void3_t;
 
 __device__ __forceinline__ void slab_dma16(const void* gsrc, unsigned lds_addr) {
-#ifdef METRO_DBG_SLAB_NO_DMA
-    asm volatile("" ::"v"(gsrc), "s"(lds_addr));
-    return;
-#endif
     asm volatile(
         "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
@@ -51,11 +47,7 @@ __device__ __forceinline__ void slab_dma16(const void* gsrc, unsigned lds_addr) 
 
 template <int N>
 __device__ __forceinline__ void slab_wait_barrier() {
-#ifdef METRO_DBG_SLAB_NO_BARRIER
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-#endif
 }
 
 // WM: 32-row cout tiles per wave (TM = WAVES_M*WM*32); pixels: TN = WAVES_N * WN * 32 (256 or 512)
@@ -296,29 +288,15 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
                 half8_t af[Cfg::WM], bf[Cfg::WN];
-#ifdef METRO_DBG_SLAB_NO_FRAG
-#pragma unroll
-                for (int i = 0; i < Cfg::WM; ++i) { af[i] = half8_t{(half_t)1, (half_t)2, (half_t)3, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(af[i]) : "v"(pa[i])); }
-#pragma unroll
-                for (int j = 0; j < Cfg::WN; ++j) { bf[j] = half8_t{(half_t)1, 0, (half_t)3, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(bf[j]) : "v"(pb[j])); }
-#else
 #pragma unroll
                 for (int i = 0; i < Cfg::WM; ++i) af[i] = *reinterpret_cast<const half8_t*>(smem + (pa[i] ^ (kk << 5)));
 #pragma unroll
                 for (int j = 0; j < Cfg::WN; ++j) bf[j] = *reinterpret_cast<const half8_t*>(smem + (pb[j] ^ (kk << 5)));
-#endif
-#ifdef METRO_DBG_SLAB_NO_MFMA
-#pragma unroll
-                for (int i = 0; i < Cfg::WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < Cfg::WN; ++j) asm volatile("" : "+v"(acc[i][j]) : "v"(af[i]), "v"(bf[j]));
-#else
 #pragma unroll
                 for (int i = 0; i < Cfg::WM; ++i)
 #pragma unroll
                     for (int j = 0; j < Cfg::WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-#endif
                 if constexpr (decltype(issue_slab_c)::value) {
                     if (tt == 0) issue_slab_part(slab_buf ^ 1, kk, kk == NKK - 1);
                 }

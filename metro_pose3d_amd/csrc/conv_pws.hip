@@ -190,7 +190,6 @@ __global__ __launch_bounds__(pws::NT) void conv_pws_kernel(PwsArgs a) {
         floatx16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const char* xl = smem + L::X_OFF + slot * X_BYTES;
         // During its GEMM phase this wave is ALONE on the matrix pipe of its SIMD (the other wave is in its epilogue): nothing hides an
         // LDS round trip, so the B fragments run DEPTH k steps ahead of their MFMA through a register ring.  Reads and waits are
         // inline asm with counted lgkmcnt: hipcc's own schedule requests a fragment one or two MFMAs ahead (~100 cycles per 32-cycle

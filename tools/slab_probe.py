@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the 3x3 stride-1 layers of blocks 2-4 alone (conv3x3_f16_slab.hip), e.g. under the knock-out builds of
-tools/build_dbg_variants.sh conv3x3_f16_slab.hip SLAB_NO_DMA SLAB_NO_MFMA SLAB_NO_FRAG SLAB_NO_BARRIER:   python tools/slab_probe.py [batch]"""
+tools/knockouts_r05.patch + tools/build_dbg_variants.sh conv3x3_f16_slab.hip SLAB_NO_DMA SLAB_NO_MFMA SLAB_NO_FRAG SLAB_NO_BARRIER:   python tools/slab_probe.py [batch]"""
 import ctypes as C
 import sys
 import numpy as np
