@@ -507,8 +507,11 @@ int build_plan(MetroPlan* p) {
             const bool chain_mid = chain == 1 && u == 2 && conv1_done && !project && s == 1 && r == 1;
             if (chain == 1 && !chain_mid) { set_error("internal: block1 rebuild chain planned for a unit 2 that is not plain"); return METRO_ERR_STATE; }
             const int nxt_slot = chain_mid ? S_X1 : nxt;      // unit 2 of the chain: S_X0 still holds x0, which its launch reads
+            // (round 5: block4's pair too -- 1024 -> 2048 + 512 in one conv_gemm4w launch: the 134 MB input read once, one launch
+            // fewer; same-box A/B batch 256 -0.4 %, batch 64 0; 1024 = the round-4 plan)
+            static const int pair_max_cout = tuning_knob("METRO_PAIR_MAX_COUT", 2048);
             const bool fuse_pair = fast && project && s == 1 && cout % 256 == 0 && cur_c % 64 == 0 && !unit_fused &&
-                                   ((cb % 128 == 0 && cout <= 1024) || pw_pair);
+                                   ((cb % 128 == 0 && cout <= pair_max_cout) || pw_pair);
             if (unit_fused) {
                 // conv1 runs inside the conv2 launch below
             } else if (conv1_done) {
