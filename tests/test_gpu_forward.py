@@ -285,7 +285,7 @@ def test_race_screen_repeated_runs_are_bit_identical(cuda):
         assert torch.equal(out, ref), f'launch {i} differs: max |d| {(out - ref).abs().max().item()}'
     # layer outputs too (a wrong tile can be averaged away by the soft-argmax)
     n_layers = len(eng.layer_infos())
-    for li in sorted({0, 1, 5, 6, 20, 30, 45, n_layers - 3, n_layers - 2}):
+    for li in sorted({0, 1, 5, 6, 20, 30, n_layers - 4, n_layers - 3, n_layers - 2}):
         a = eng.forward_upto(x, li)
         for _ in range(5):
             assert torch.equal(eng.forward_upto(x, li), a), f'layer {li} not deterministic'
@@ -304,12 +304,12 @@ def test_race_screen_batch64_persistent_kernels(cuda):
                                                      'block1/unit_3/conv3', 'block2/unit_2/conv3+unit_3/conv1', 'block3/unit_2/conv2',
                                                      'block3/unit_3/conv3', 'block4/unit_2/conv3', 'logits',
                                                      'block1/unit_2/conv2',          # conv3x3_c64: persistent, double-buffered slabs
-                                                     'block4/unit_1/shortcut')]      # conv_gemm8p: two wave groups, vmcnt(6) ring
+                                                     'block4/unit_1/shortcut+conv1')]   # conv_gemm4w pair: register-staged K tiles
     assert len(picks) == 12
     ref = eng.forward(x).clone()
     refs = {i: eng.forward_upto(x, i).clone() for i in picks}
     seconds = {i: eng.forward_upto(x, i, second=True).clone() for i in picks if eng.layer_infos()[i].out2_offset >= 0}
-    assert torch.isfinite(ref).all() and len(seconds) == 4
+    assert torch.isfinite(ref).all() and len(seconds) == 5
     junk = torch.empty(256 << 20, dtype=torch.uint8, device=cuda)
     for it in range(12):
         if it % 2 == 0:
