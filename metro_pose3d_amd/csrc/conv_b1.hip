@@ -213,26 +213,18 @@ __global__ __launch_bounds__(b1::NT) void conv_b1_chain_kernel(B1Args a) {
         for (int j = 0; j <= T; ++j) {
             // tile j's operands have landed (this wave's share; the barrier makes it every producer's) and the consumers are done
             // with the LDS tile of j - 2, which tile j overwrites
-#ifndef METRO_DBG_B1_NO_DMA
             if (j < T) {
                 if (j + 1 < T) b1_wait_vm<NIN>();            // tile j + 1's requests may stay in flight
                 else b1_wait_vm<0>();
             }
-#endif
             if (j < T) {
                 half8_t* mine = reinterpret_cast<half8_t*>(smem + L::X_OFF + (slot * NIN + 1) * X_BYTES + wave * 1024 + lane * 16);
                 const half8_t z = {};
                 *mine = __builtin_elementwise_max(*mine * pre_s + pre_b, z);
             }
             b1_barrier();
-#ifndef METRO_DBG_B1_NO_DMA
             if (j + 2 < T) issue_tile(t0 + (j + 2) * G, slot >= 1 ? slot - 1 : 2);       // slot of j + 2 = (slot + 2) % 3
-#endif
-#ifdef METRO_DBG_B1_NO_PRODUCER
-            if (false) {
-#else
             if (j < T) {
-#endif
                 const char* xs = smem + L::X_OFF + slot * NIN * X_BYTES;
                 char* ot = smem + L::OUT_OFF + (j & 1) * OUT_BYTES;
                 floatx16 acc[2];                             // [pixel half]
@@ -314,9 +306,6 @@ __global__ __launch_bounds__(b1::NT) void conv_b1_chain_kernel(B1Args a) {
         for (int j = 0; j <= T; ++j) {
             b1_barrier();                                   // tile j - 1's sum is complete in its LDS tile
             if (j == 0) continue;
-#ifdef METRO_DBG_B1_NO_CONSUMER
-            continue;
-#endif
             // ---- 16 pixels of tile j - 1 x all channels: store | pre-activate | conv1 of the next unit -------------------------------
             const int tile = t0 + (j - 1) * G;
             const char* ot = smem + L::OUT_OFF + ((j - 1) & 1) * OUT_BYTES;

@@ -189,20 +189,14 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
             constexpr int first[4] = {0, 3, 6, 8};
             constexpr int NP = first[kk + 1] - first[kk];
             load_frags((kk + 1) & 1, BUF, kk + 1);
-#ifndef METRO_DBG_G4_NO_WRITE
 #pragma unroll
             for (int e = first[kk]; e < first[kk + 1]; ++e) store_piece(BUF ^ 1, SET, e);
-#endif
-#ifndef METRO_DBG_G4_NO_LOAD
 #pragma unroll
             for (int e = first[kk]; e < first[kk + 1]; ++e) {
                 ra[SET][e] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, e * piece_stride + knext, 0);
                 rb[SET][e] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, e * piece_stride + knext, 0);
             }
-#endif
-#ifndef METRO_DBG_G4_NO_MFMA
             mma(kk & 1);
-#endif
             // emitted order of the step: a fragment read (and the pre-activation VALU of the pieces about to be written) behind each
             // of the first 8 MFMAs, then one LDS write + one request behind each of the next ones
             if (PROLOGUE && kk == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // this tile's scale / shift
@@ -227,11 +221,7 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
         step(std::integral_constant<int, 2>{});
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         load_frags(0, BUF ^ 1, 0);
-#ifndef METRO_DBG_G4_NO_MFMA
         mma(1);                                  // k step 3: fragments read before the barrier
-#else
-        asm volatile("" ::"v"(af[0][0]), "v"(bf[0][0]), "v"(af[1][3]), "v"(bf[1][3]));
-#endif
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

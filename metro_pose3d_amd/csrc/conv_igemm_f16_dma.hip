@@ -71,9 +71,6 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // is invisible to its bookkeeping; completion is ordered by the counted waits below.
 // lds_addr must be wave-uniform (it goes through M0, saved/restored around the instruction).
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_addr) {
-#ifdef METRO_DBG_SKIP_LOAD    // timing experiments only (tools/build_dbg_variants.sh): results are garbage
-    return;
-#endif
     // M0 is written in the same statement that consumes it and is not preserved: nothing else in
     // these kernels uses M0 (gfx9+ LDS instructions do not need it).
     asm volatile(
@@ -296,11 +293,7 @@ __device__ __forceinline__ void conv_dma_body(
             for (int i = 0; i < Cfg::WM; ++i)
 #pragma unroll
                 for (int j = 0; j < Cfg::WN; ++j)
-#ifdef METRO_DBG_SKIP_MFMA
-                    acc[i][j][0] += (float)af[i][0] * (float)bf[j][0];
-#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-#endif
 #ifdef METRO_SETPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
@@ -564,9 +557,6 @@ __device__ __forceinline__ void conv_dma_body(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] = x[e] + r[e];    // fp16 Add, like the reference graph
                 }
-#ifdef METRO_DBG_SKIP_STORE
-                if (a.m_total < 0)
-#endif
                 store_out16<2>(outh + (size_t)(m0 + prow) * o_c + o_n0 + ch * 8, v);
                 if constexpr (FUSE2) *reinterpret_cast<uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16) = v;
             }
@@ -588,9 +578,6 @@ __device__ __forceinline__ void conv_dma_body(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = x[e] + r[e];    // fp16 Add, like the reference graph
             }
-#ifdef METRO_DBG_SKIP_STORE
-            if (a.m_total < 0)
-#endif
             store_out16<2>(outh + (size_t)m * o_c + co, v);
             if constexpr (FUSE2) *reinterpret_cast<uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16) = v;
         } else {

@@ -380,14 +380,10 @@ __global__ __launch_bounds__(hd2::NT) void head_f16_kernel256(HeadArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (i < na) {
-#ifndef METRO_DBG_HD2_NO_W
                 hd_dma16(srcw[i], base + (wave + NW * i) * 16 * ROW_BYTES);
-#endif
                 srcw[i] += incw[i];
             }
-#ifndef METRO_DBG_HD2_NO_X
             hd_dma16(srcx[i], base + TM * ROW_BYTES + (wave + NW * i) * 16 * ROW_BYTES);
-#endif
             srcx[i] += BK;
         }
     };
@@ -425,11 +421,7 @@ __global__ __launch_bounds__(hd2::NT) void head_f16_kernel256(HeadArgs a) {
             for (int i = 0; i < MT; ++i) {
                 const int row = i * 32 + frag_row;
                 const half8_t af = *reinterpret_cast<const half8_t*>(wl + row * ROW_BYTES + ((chunk ^ hd2_swz(row)) << 4));
-#ifndef METRO_DBG_HD2_NO_MFMA
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[i], 0, 0, 0);
-#else
-                acc[i][0] += (float)af[0] * (float)bf[0];
-#endif
             }
         }
     };
@@ -463,9 +455,6 @@ __global__ __launch_bounds__(hd2::NT) void head_f16_kernel256(HeadArgs a) {
     float* lt = reinterpret_cast<float*>(smem) + (wave & 3) * (32 * LROW);
     const float step_s = 1.0f / (float)(a.side - 1);
     const float step_d = 1.0f / (float)(a.D - 1);
-#ifdef METRO_DBG_HD2_NO_SOFTMAX
-    if (a.J > 0) { if (tid == 0) a.partials[0] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + acc[4][4]; return; }
-#endif
     for (int round = 0; round < 2; ++round) {
         if ((wave >> 2) == round) {
 #pragma unroll
@@ -618,17 +607,13 @@ __global__ __launch_bounds__(512, 2) void head_f16_ring_kernel(HeadArgs a) {
         const unsigned base = lds_wave + slot_off;
         const half_t* xs = xbase + kt * BK;
         const half_t* ws = a.w + kt * BK;
-#ifndef METRO_DBG_HD3_NO_X
         hd_dma16s<WROWS * ROW_BYTES + 0 * 8192>(xs, voffx[0], base);      // the pixel rows first: first touch from HBM
         if constexpr (G::NB > 1) hd_dma16s<WROWS * ROW_BYTES + 1 * 8192>(xs, voffx[1], base);
         if constexpr (G::NB > 2) hd_dma16s<WROWS * ROW_BYTES + 2 * 8192>(xs, voffx[2], base);
         if constexpr (G::NB > 3) hd_dma16s<WROWS * ROW_BYTES + 3 * 8192>(xs, voffx[3], base);
-#endif
-#ifndef METRO_DBG_HD3_NO_W
         hd_dma16s<0 * 8192>(ws, voffw[0], base);
         hd_dma16s<1 * 8192>(ws, voffw[1], base);
         if (na == 3) hd_dma16s<2 * 8192>(ws, voffw[2], base);
-#endif
     };
     static_assert(G::NA_LO == 2, "two weight groups per wave at least, a third for the first GA % 8 waves");
     constexpr int NW_LO = G::NA_LO + G::NB, NW_HI = G::NA_HI + G::NB;     // DMA instructions per wave and K step
@@ -653,12 +638,8 @@ __global__ __launch_bounds__(512, 2) void head_f16_ring_kernel(HeadArgs a) {
     }
 #pragma unroll
     for (int st = 0; st < STAGES; ++st) issue_step(st * STAGE_BYTES, st < nk ? st : nk - 1);
-#if defined(METRO_DBG_HD3_NO_X) || defined(METRO_DBG_HD3_NO_W)
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#else
     if (na_hi) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 1) * NW_HI) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((STAGES - 1) * NW_LO) : "memory");
-#endif
     const float* bias_lds = reinterpret_cast<const float*>(smem + G::BIAS_OFF);
 
     // fragment addresses inside a stage, per phase of the wave's K-part (ph: the 16-byte chunk (h NP + ph) 2 + lane half)
@@ -700,13 +681,8 @@ __global__ __launch_bounds__(512, 2) void head_f16_ring_kernel(HeadArgs a) {
     };
     auto mma = [&](auto par_c, auto i_c) {
         constexpr int P = decltype(par_c)::value, I = decltype(i_c)::value;
-#ifndef METRO_DBG_HD3_NO_MFMA
 #pragma unroll
         for (int t = 0; t < PT; ++t) acc[t][I] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[P][I], bq[P][t], acc[t][I], 0, 0, 0);
-#else
-        const half8_t a_ = af[P][I], b0_ = bq[P][0], b1_ = bq[P][PT - 1];
-        asm volatile("" ::"v"(a_), "v"(b0_), "v"(b1_));
-#endif
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -734,11 +710,7 @@ __global__ __launch_bounds__(512, 2) void head_f16_ring_kernel(HeadArgs a) {
         mma(par_c, I2{});
         hd_pin<1, PT, 4>();
         if constexpr (LAST) {
-#if defined(METRO_DBG_HD3_NO_X) || defined(METRO_DBG_HD3_NO_W)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
             if (na_hi) hd_wait_barrier<(STAGES - 2) * NW_HI>(); else hd_wait_barrier<(STAGES - 2) * NW_LO>();
-#endif
             issue_step(cur, k + STAGES < nk ? k + STAGES : nk - 1);
         }
         rd_a(PQ{}, I0{}, noff, NPH{});
@@ -785,9 +757,6 @@ __global__ __launch_bounds__(512, 2) void head_f16_ring_kernel(HeadArgs a) {
     float* lt0 = reinterpret_cast<float*>(smem) + pg * (KSPLIT - 1) * (32 * LROW);     // the group's tiles: part h writes tile h - 1
     const float step_s = 1.0f / (float)(a.side - 1);
     const float step_d = 1.0f / (float)(a.D - 1);
-#ifdef METRO_DBG_HD3_NO_SOFTMAX
-    if (a.J > 0) { float v = 0.f; for (int t = 0; t < PT; ++t) for (int i = 0; i < MT; ++i) v += acc[t][i][t + i]; if (v == 12345.f) a.partials[tid] = v; return; }
-#endif
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (h > 0) {

@@ -128,9 +128,6 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
             wf[i][kk] = *reinterpret_cast<const half8_t*>(a.w + (size_t)((ct0 + i) * 32 + frag_row) * 224 + kk * 16 + frag_half * 8);
     float* bias_l = reinterpret_cast<float*>(smem + BIAS_OFF);
     if (tid < 64) bias_l[tid] = a.bias[tid];
-#if defined(METRO_DBG_SP_SKIP_CONV) || defined(METRO_DBG_SP_SKIP_CONVWRITE)
-    for (int i = tid; i < CONV_BYTES / 16; i += NT) reinterpret_cast<uint4*>(smem + CONV_OFF)[i] = make_uint4(0, 0, 0, 0);
-#endif
 
     // window chunk c = q*64 + lane (q = wave + 4*i): window row c / 20, pixel pair c % 20
     auto issue_window = [&](int patch, int buf) {
@@ -146,11 +143,7 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
                 const int wr = c / (WIN_C / 2), wc = (c - wr * (WIN_C / 2)) * 2;
                 const int y = r0 + wr, x = c0 + wc;
                 const bool ok = c < WIN_CHUNKS && (unsigned)y < (unsigned)hp && (unsigned)x < (unsigned)wp;
-#ifdef METRO_DBG_SP_LINEAR_WINDOW   // timing experiment: same bytes, contiguous source
-                sp_dma16(ok ? a.img + ((size_t)(patch % (a.n * 8 * 8)) * WIN_BYTES / 2 + c * 8) : zero,
-#else
                 sp_dma16(ok ? base + ((size_t)y * wp + x) * 4 : zero,
-#endif
                          __builtin_amdgcn_readfirstlane(smem_base + WIN_OFF + buf * WIN_BYTES + q * 1024));
             }
         }
@@ -229,11 +222,7 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
             half4_t hv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) hv[e] = (half_t)(acc[i][4 * q + e] + bv[e]);
-#ifdef METRO_DBG_SP_SKIP_CONVWRITE
-            if (m < CPIX && a.n < 0)
-#else
             if (m < CPIX)
-#endif
                 *reinterpret_cast<half4_t*>(cl + m * CONV_ROW + co * 2) = hv;
         };
         auto conv_tile = [&](int mt, floatx16 (&acc)[CT], int& m, auto with_prev, const floatx16 (&pacc)[CT], int pm) {
@@ -245,21 +234,13 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 const half8_t bf = *reinterpret_cast<const half8_t*>(bp + (kk >> 1) * WIN_ROW_BYTES + (kk & 1) * 32);
-#ifdef METRO_DBG_SP_SKIP_MFMA      // timing experiments only (tools/build_dbg_variants.sh)
-#pragma unroll
-                for (int i = 0; i < CT; ++i) acc[i][0] += (float)bf[i] * (float)wf[i][kk][0];
-#else
 #pragma unroll
                 for (int i = 0; i < CT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i][kk], bf, acc[i], 0, 0, 0);
-#endif
                 if constexpr (decltype(with_prev)::value) {
                     if (kk >= 2 && kk < 2 + 4 * CT) epi_part(pacc, pm, kk - 2);
                 }
             }
         };
-#ifdef METRO_DBG_SP_SKIP_CONV
-        if (a.n < 0)
-#endif
         {
             using Yes = std::integral_constant<bool, true>;
             using No = std::integral_constant<bool, false>;
@@ -297,9 +278,6 @@ __global__ __launch_bounds__(64 * sp::MG * NSPLIT, 2 * NSPLIT) void stem_pool_f1
             const int ppy = pp >> 3, ppx = pp & 7;
             // out-of-image conv positions contribute 0 (mask, no branches: all 9 reads are issued back to back)
             half8_t best = {};
-#ifdef METRO_DBG_SP_SKIP_POOL
-            if (a.n < 0)
-#endif
             {
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {           // one window row at a time (3 reads in flight: registers)
@@ -413,9 +391,6 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
     const float* crop = a.img_f32 + (size_t)img * SIDE * SIDE * 3;
     // crop row i (clamped: rows outside the crop are cast to zeros whatever arrived) -> a staging slot: waves 0-2 a KiB each
     auto issue_row = [&](int i, int slot) {
-#ifdef METRO_DBG_SP2_NO_DMA
-        if (a.n < 0)
-#endif
         if (wave < 3) {
             const int ic = i < 0 ? 0 : i > SIDE - 1 ? SIDE - 1 : i;
             const float* src = crop + (size_t)ic * SIDE * 3 + wave * 256 + lane * 4;
@@ -440,16 +415,10 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
         for (int r = 0; r < 4; ++r) issue_row(4 * (Y0 + t) + 6 + r, (t % 3) * 4 + r);
     };
     auto cast_group_read = [&](int t, half4_t (&v)[4]) {
-#ifdef METRO_DBG_SP2_NO_CAST
-        if (a.n < 0)
-#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) cast_read(4 * (Y0 + t) + 9 + r, (t % 3) * 4 + r, v[r]);
     };
     auto cast_group_write = [&](int t, const half4_t (&v)[4]) {
-#ifdef METRO_DBG_SP2_NO_CAST
-        if (a.n < 0)
-#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) cast_write(4 * (Y0 + t) + 9 + r, v[r]);
     };
@@ -539,13 +508,8 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
         for (int kk = 0; kk < KK; ++kk) {
             if (kk + SP2_PF - 1 < KK) pf[(kk + SP2_PF - 1) % SP2_PF] = frag(kk + SP2_PF - 1);
             asm volatile("" ::: "memory");          // the read stays ahead of this k-step's MFMAs
-#ifdef METRO_DBG_SP2_NO_MFMA      // timing experiments only (tools/build_dbg_variants.sh)
-            acc[0][kk] += (float)pf[kk % SP2_PF][0] * (float)wf[0][kk][0];
-            acc[1][kk] += (float)pf[kk % SP2_PF][1] * (float)wf[1][kk][1];
-#else
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[kk % SP2_PF], wf[0][kk], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[kk % SP2_PF], wf[1][kk], acc[1], 0, 0, 0);
-#endif
         }
         if constexpr (decltype(pin_c)::value) {      // on its own: the emitted order (with the pooling: pinned by the caller)
             __builtin_amdgcn_sched_group_barrier(0x100, SP2_PF - 1, 0);
@@ -575,10 +539,6 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
 #pragma unroll
         for (int f = 0; f < 18; ++f) {
             if (f + SP2_PF - 1 < 18) pf[(f + SP2_PF - 1) % SP2_PF] = frag(f + SP2_PF - 1);
-#ifdef METRO_DBG_SP2_NO_MFMA      // timing experiments only (tools/build_dbg_variants.sh)
-            accA[0][f & 15] += (float)pf[f % SP2_PF][0] * (float)wf[0][f % KK][0];
-            accB[1][f & 15] += (float)pf[f % SP2_PF][1] * (float)wf[1][f % KK][1];
-#else
             if (f < KK) {
                 accA[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[f % SP2_PF], wf[0][f < KK ? f : 0], accA[0], 0, 0, 0);
                 accA[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[f % SP2_PF], wf[1][f < KK ? f : 0], accA[1], 0, 0, 0);
@@ -587,7 +547,6 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
                 accB[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[f % SP2_PF], wf[0][f >= 4 ? f - 4 : 0], accB[0], 0, 0, 0);
                 accB[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf[f % SP2_PF], wf[1][f >= 4 ? f - 4 : 0], accB[1], 0, 0, 0);
             }
-#endif
         }
         // the emitted order: fragment reads SP2_PF - 1 ahead of their MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, SP2_PF - 1, 0);
@@ -611,11 +570,6 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
     // bias, fp16 (the value the reference's conv stores) and the horizontal 3-max of a conv row: branch-free, so that it can sit in
     // the shadow of the next row's MFMAs.  hp[i][q] = pooled columns (2g, 2g + 1) of channel tile i; eh[i].hi = the tile's last O
     auto hmax_row = [&](const floatx16 (&acc)[2], half2_t (&hp)[2][4], half2_t (&eh)[2]) {
-#ifdef METRO_DBG_SP2_NO_POOL
-        if (acc[0][0] + acc[1][1] + acc[0][5] + acc[1][9] == 12345.f) a.out[tid] = (half_t)1;
-        for (int i = 0; i < 2; ++i) { for (int q = 0; q < 4; ++q) hp[i][q] = zero2; eh[i] = zero2; }
-        return;
-#endif
         half2_t P0[2][4], P1[2][4], R[2][4];             // (E[2g], O[2g]), (E[2g+1], O[2g+1]) per quad; the other half's P1
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -669,13 +623,7 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
         }
     };
 
-#ifdef METRO_DBG_SP2_CLOCK      // timing experiment: s_memtime at six points of every iteration, summed per interval (wave 0 of block 1)
-    long long clk_sum[6] = {0, 0, 0, 0, 0, 0}, clk_prev = 0, clk_start = __builtin_readcyclecounter();
-    const long long rt_start = __builtin_amdgcn_s_memrealtime();
-#define SP2_CLK(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); if (i) clk_sum[i] += t_ - clk_prev; clk_prev = t_; } while (0)
-#else
 #define SP2_CLK(i) do { } while (0)
-#endif
     floatx16 accA[2], accB[2];
     // ---- the conv row above the band: only feeds the carry (band 0: the pool's zero row is the initial carry) ----
     if (Y0 > 0) {
@@ -717,7 +665,6 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
         SP2_CLK(4);
         // vertical 3-max; lane n holds (X, X + 1) of channel n: the lane pair (n, n ^ 1) swaps one column so that the even lane
         // writes column X of channels (n, n + 1) and the odd lane column X + 1 of (n - 1, n): one 4-byte write per quad
-#ifndef METRO_DBG_SP2_NO_POOL
         sp_barrier();            // every wave has read the last pooled row out of the tile (at the top of this iteration)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -733,7 +680,6 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
             if (hh == 0) *reinterpret_cast<half_t*>(smem + EDGE_OFF + wave * 128 + (i * 32 + n) * 2) = ep[1];
             ecarry[i] = ehB[i];
         }
-#endif
         SP2_CLK(5);
     }
     sp_barrier();
@@ -742,19 +688,6 @@ __global__ __launch_bounds__(sp2::NT, 2) void stem_pool_rows_kernel(StemPoolArgs
         store_read(sv);
         store_write(Y0 + PY - 1, sv);       // the band's last pooled row
     }
-#ifdef METRO_DBG_SP2_CLOCK
-    if (tid == 0) {      // per block: start, end (100 MHz wall clock), HW_ID, XCC_ID -- behind the first 64 bytes
-        long long* blk = reinterpret_cast<long long*>(a.out) + 8 + blockIdx.x * 4;
-        blk[0] = rt_start; blk[1] = __builtin_amdgcn_s_memrealtime();
-        blk[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); blk[3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
-    }
-    if (blockIdx.x == 1 && tid == 0) {
-        long long* dbg = reinterpret_cast<long long*>(a.out);
-        for (int i = 0; i < 6; ++i) dbg[i] = clk_sum[i];
-        dbg[6] = __builtin_readcyclecounter() - clk_start;
-        dbg[7] = PY;
-    }
-#endif
 #undef SP2_CLK
 }
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the METRO_DBG_* sites live in tools/knockouts_r02_r04.patch, not in the product sources: see tools/build_dbg_variants.sh)
 # Timing experiments on conv_gemm4d (results of the knock-out builds are garbage): which part of the K loop costs what.
 #   tools/gemm4d_knockouts.sh    (on the GPU box; builds the variants first if hipcc is there)
 cd "$(dirname "$0")/.."

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the METRO_DBG_* sites live in tools/knockouts_r02_r04.patch, not in the product sources: see tools/build_dbg_variants.sh)
 # Timing experiments on the 256-pixel K-halves head (results of the knock-out builds are garbage): which part costs what.
 #   tools/head_knockouts.sh    (on the GPU box; the variants are built here first: tools/build_dbg_variants.sh head_f16.hip ...)
 cd "$(dirname "$0")/.."

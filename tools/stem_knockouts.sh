@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the METRO_DBG_* sites live in tools/knockouts_r02_r04.patch, not in the product sources: see tools/build_dbg_variants.sh)
 # Timing experiments on the rows stem (results of the knock-out builds are garbage): which part of a conv-row iteration costs what.
 #   tools/stem_knockouts.sh   (variants built here first: tools/build_dbg_variants.sh stem_pool_f16.hip SP2_NO_MFMA ...)
 cd "$(dirname "$0")/.."
