@@ -156,11 +156,13 @@ def _dev(a, cuda, dt):
     return torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(cuda)
 
 
-@pytest.mark.parametrize('shape', [(3, 7, 64, 256, 64), (25, 64, 64, 256, 64), (2, 16, 256, 512, 128), (3, 9, 512, 1024, 256)],
-                         ids=['block1_ragged', 'block1_many_tiles', 'block2', 'block3_ragged'])
+@pytest.mark.parametrize('shape', [(3, 7, 64, 256, 64), (25, 64, 64, 256, 64), (2, 16, 256, 512, 128), (3, 9, 256, 512, 128),
+                                   (40, 32, 256, 512, 128), (3, 9, 512, 1024, 256)],
+                         ids=['block1_ragged', 'block1_many_tiles', 'block2', 'block2_ragged', 'block2_many_tiles', 'block3_ragged'])
 def test_conv_f16_pair(lib, cuda, shape):
     """Projection shortcut + conv1 of a unit in one launch (reference resnet_v2.py:122-128): both outputs
-    against the fp64 reference on the same fp16 operands.  64 -> 256+64 runs in the persistent kernel."""
+    against the fp64 reference on the same fp16 operands.  64 -> 256+64 and (round 5) 256 -> 512+128 run in the persistent
+    weight-resident kernel: a ragged last tile (243 pixels) and more tiles than blocks (40 960 pixels = 5 tiles per block)."""
     n, h, c_in, c_sc, cb = shape
     rng = np.random.default_rng(zlib.crc32(repr(shape).encode()))
     x, w, b = _mk(rng, n, h, c_in, c_sc + cb, 1)
