@@ -1,0 +1,48 @@
+"""profiles/roofline_floors.py (the per-launch floors made reproducible) runs without a GPU on the committed
+counter tables and reads the workload -- the batch above all: FLOPs scale with it -- off the table's name."""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(table, *extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'profiles', 'roofline_floors.py'), table, *extra], capture_output=True, text=True,
+                       cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l.split('\t') for l in r.stdout.splitlines() if '\t' in l]
+    total = [x for x in rows if x[0] == 'TOTAL'][0]
+    return rows, total, r.stdout
+
+
+def _latest(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+    if not files:
+        pytest.skip(f'no committed table matches profiles/{pattern}')
+    return files[-1]
+
+
+def test_floors_of_the_batch256_table_use_batch256_flops():
+    table = _latest('r0*_b256_pmc_layers.tsv')
+    rows, total, out = _run(table)
+    # RN50-s16-J17: 15.299 GFLOP per crop x 256 crops (metro_plan_flops_per_image), whatever the launch set looks like
+    assert abs(float(total[2]) - 15.299 * 256) < 2.0, total
+    assert 'sum of per-launch floors' in out
+    frac = float(total[7])
+    assert 0.3 < frac < 1.0, total
+    # the measured ceilings can only raise the ratio
+    _, total2, _ = _run(table, '--mfma-tflops', '1700', '--hbm-gbs', '4500')
+    assert float(total2[7]) > frac
+
+
+def test_floors_of_the_default_table_use_batch64_flops():
+    tables = [t for t in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r0*_pmc_layers.tsv')))
+              if not any(tag in os.path.basename(t) for tag in ('_b256_', '_c3_', '_c4_', '_c5_'))]
+    if not tables:
+        pytest.skip('no committed batch-64 table')
+    _, total, _ = _run(tables[-1])
+    assert abs(float(total[2]) - 15.299 * 64) < 1.0, total
