@@ -171,7 +171,7 @@ int  metro_plan_bind_params(MetroPlan* plan, const void* d_param_blob);
  *      d_images_nhwc: fp32 [n,256,256,3] in [0,1];  d_poses_out: fp32 [n,Jout,3] in mm. ---- */
 int  metro_forward(MetroPlan* plan, const float* d_images_nhwc, int32_t n, float* d_poses_out,
                    void* d_workspace, void* stream);
-/* Small batches are launch-latency bound (57 dependent launches for ResNet-50): forwards with
+/* Small batches are launch-latency bound (45 dependent launches for ResNet-50 stride 16): forwards with
  * n <= max_batch_for_graphs are captured once per (n, buffers, stream) into a hipGraph and replayed.
  * 0 (default) = always plain launches.  The capture happens on the second call with a given key. */
 int  metro_plan_set_graph_max_batch(MetroPlan* plan, int32_t max_batch_for_graphs);

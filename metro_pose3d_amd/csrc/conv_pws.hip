@@ -248,7 +248,9 @@ bool conv_pws_supported(const MetroConvDesc& d) {
     // K = 256 (block3): at batch 256 the lock-step kernel already runs at its HBM roof (302 MB in 67 us) and this one loses the
     // full-line stores (64-byte row pieces per wave): 68 -> 74 us, step +1 %; at batch 64 (8 work items per block: ramp and drain
     // count) it wins, 23.3 -> 21 us, step -0.55 %.  Same bits either way, so the choice may follow the batch.
-    static const int k256_max_items = tuning_knob("METRO_PWS_K256_MAX_ITEMS", 12);
+    // (round 5, after the weight staging: at 16 work items per block -- RN101-s8 at batch 32, RN50-s16 at batch 128 -- the skewed kernel
+    // still wins, -1.7 % / -1.0 % of the step; at 32 (batch 256) the lock-step one does, +1.3 %: profiles/r05_ab_pws_k256_items.txt)
+    static const int k256_max_items = tuning_knob("METRO_PWS_K256_MAX_ITEMS", 16);
     if (d.c_in == 512) return true;
     const long items = (m / pws::TN) * (d.c_out / pws::CB);
     return items <= (long)k256_max_items * 256;
