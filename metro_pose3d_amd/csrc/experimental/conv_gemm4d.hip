@@ -88,7 +88,11 @@ __device__ __forceinline__ void g4d_for(F&& f) {
     }
 }
 
-template <bool PROLOGUE, int MI, int NJ>
+// INPLACE (round 5, experiment): the pre-activation is applied ONCE per element, in place in the landed pixel image, by the wave whose
+// LDS-DMA brought the rows in (8 pieces of 1 KiB per wave and K tile: read - 8 packed ops - write, software-pipelined through the
+// four MFMA segments of k step 1 behind a counted vmcnt that leaves the cout requests in flight) instead of on every fragment read
+// (each pixel fragment is read by the two waves of a pixel half: twice the VALU work, and on the MFMA wave's critical path).
+template <bool PROLOGUE, int MI, int NJ, bool INPLACE = false>
 __global__ __launch_bounds__(g4d::NT, (MI * NJ <= 4 ? 2 : 1)) void conv_gemm4d_kernel(
     ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w, const float* __restrict__ bias,
     const half_t* __restrict__ pro_scale, const half_t* __restrict__ pro_shift, const half_t* __restrict__ residual,
@@ -172,6 +176,21 @@ __global__ __launch_bounds__(g4d::NT, (MI * NJ <= 4 ? 2 : 1)) void conv_gemm4d_k
         b_base[j] = G::B_BASE + row * ROW_BYTES + ((frag_half ^ g4d_swz(row)) << 4);
     }
 
+    // INPLACE: this wave's own pixel pieces of a K tile (piece g: rows 32 g + 8 wave + (lane >> 3), physical chunk lane & 7 -- the
+    // logical chunk, hence the lane's 8 channels, is the same for all eight pieces: swz(row) does not see g)
+    const int rmw_chunk = lch ^ ((wave * 4 + (lrow >> 1)) & 7);
+    half8_t prs = {}, prh = {};
+    half8_t rp[G::RB];
+    auto rmw_pro = [&](int kt) {
+        prs = *reinterpret_cast<const half8_t*>(pro_lds + kt * BK + rmw_chunk * 8);
+        prh = *reinterpret_cast<const half8_t*>(pro_lds + 2048 + kt * BK + rmw_chunk * 8);
+    };
+    auto rmw_addr = [&](int buf, int g) { return smem + G::B_BASE + buf * G::OPER_B + g * 4096 + wave * 1024 + lane * 16; };
+    auto rmw_read = [&](int buf, int g) { rp[g] = *reinterpret_cast<const half8_t*>(rmw_addr(buf, g)); };
+    auto rmw_write = [&](int buf, int g) {
+        const half8_t z = {};
+        *reinterpret_cast<half8_t*>(rmw_addr(buf, g)) = __builtin_elementwise_max(rp[g] * prs + prh, z);
+    };
     // ---- prologue: the table, K tile 0, and of tile 1 what the loop would have requested by now; tile 0 landed --------------------
     if (PROLOGUE) {
         // the pre-activation table by LDS-DMA too (wave w: 1 KiB of each vector), FIRST: a compiler-visible global load next to the
@@ -194,6 +213,14 @@ __global__ __launch_bounds__(g4d::NT, (MI * NJ <= 4 ? 2 : 1)) void conv_gemm4d_k
 #else
     g4d_wait_vm_barrier<HEAD>();                                  // tile 0 (and the table) landed everywhere
 #endif
+    if constexpr (INPLACE && PROLOGUE) {
+        rmw_pro(0);
+#pragma unroll
+        for (int g = 0; g < G::RB; ++g) rmw_read(0, g);
+#pragma unroll
+        for (int g = 0; g < G::RB; ++g) rmw_write(0, g);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 
     // FOUR fragment sets, one per k step of a K tile: while the MFMAs of k step kk run on set kk, the pixel fragments of set kk + 1
     // (read during k step kk - 1) are pre-activated and set kk + 2 is read -- neither a VALU op nor an MFMA ever waits for an LDS
@@ -202,7 +229,7 @@ __global__ __launch_bounds__(g4d::NT, (MI * NJ <= 4 ? 2 : 1)) void conv_gemm4d_k
     half8_t sc[4] = {}, sh[4] = {};      // the pre-activation of a set's 8 channels per lane
     auto read_pro = [&](auto kk_c, int kt) {
         constexpr int KK = decltype(kk_c)::value;
-        if constexpr (PROLOGUE) {
+        if constexpr (PROLOGUE && !INPLACE) {
             sc[KK] = *reinterpret_cast<const half8_t*>(pro_lds + kt * BK + KK * 16 + frag_half * 8);
             sh[KK] = *reinterpret_cast<const half8_t*>(pro_lds + 2048 + kt * BK + KK * 16 + frag_half * 8);
         }
@@ -219,7 +246,7 @@ __global__ __launch_bounds__(g4d::NT, (MI * NJ <= 4 ? 2 : 1)) void conv_gemm4d_k
     auto act_b = [&](auto kk_c, int j) {
         constexpr int KK = decltype(kk_c)::value;
 #ifndef METRO_DBG_G4D_NO_PRO
-        if constexpr (PROLOGUE) {
+        if constexpr (PROLOGUE && !INPLACE) {
             const half8_t z = {};
             bf[KK][j] = __builtin_elementwise_max(bf[KK][j] * sc[KK] + sh[KK], z);
         }
@@ -242,22 +269,33 @@ __global__ __launch_bounds__(g4d::NT, (MI * NJ <= 4 ? 2 : 1)) void conv_gemm4d_k
     // behind every segment (dma(e): request slot e of this k step, or nothing).  Memory operations do not cross an asm volatile
     // statement: reads and requests stay in the segment they are written in; the emitted order inside a segment is pinned.
     constexpr int BPS = NJ / MI > 0 ? NJ / MI : 1;          // pixel fragments read / pre-activated per segment
+    int rmw_kt = 0;                                         // INPLACE: the K tile whose pixel image k step 1 pre-activates
     auto kstep = [&](auto kk_c, auto rbuf_c, int kr, auto dma) {
         constexpr int KK = decltype(kk_c)::value;
         using S = std::integral_constant<int, KK>;
         using V = std::integral_constant<int, (KK + 1) & 3>;
         using R = std::integral_constant<int, (KK + 2) & 3>;
         using RB = decltype(rbuf_c);
+        constexpr bool RMW = INPLACE && PROLOGUE && KK == 1 && MI == 4 && NJ == 4;   // pieces 2 I, 2 I + 1 read in segment I, written in I + 1
+        constexpr int NB = RB::value ^ 1;                                             // the buffer the NEXT tile lands in
+        if constexpr (RMW) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::RA) : "memory");              // own pixel pieces landed; the cout requests may fly
+            rmw_pro(rmw_kt);
+        }
         g4d_for<MI>([&](auto i_c) {
             constexpr int I = decltype(i_c)::value;
+            if constexpr (RMW) {
+                rmw_read(NB, 2 * I); rmw_read(NB, 2 * I + 1);
+                if constexpr (I > 0) { rmw_write(NB, 2 * I - 2); rmw_write(NB, 2 * I - 1); }
+            }
             if constexpr (I == 0) read_pro(R{}, kr);
 #pragma unroll
             for (int b = 0; b < BPS; ++b)
                 if (I * BPS + b < NJ) { read_b(RB{}, R{}, I * BPS + b); act_b(V{}, I * BPS + b); }
             read_a(RB{}, R{}, I);
             mma_row(S{}, I);
-            constexpr int NREAD = BPS + 1 + ((I == 0 && PROLOGUE) ? 2 : 0);
-            constexpr int NVALU = 8 * BPS;
+            constexpr int NREAD = BPS + 1 + ((I == 0 && PROLOGUE && !INPLACE) ? 2 : 0) + (RMW ? 2 + (I == 0 ? 2 : 0) : 0);
+            constexpr int NVALU = INPLACE ? (RMW && I > 0 ? 16 : 0) : 8 * BPS;
 #pragma unroll
             for (int m = 0; m < NJ; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -267,10 +305,12 @@ __global__ __launch_bounds__(g4d::NT, (MI * NJ <= 4 ? 2 : 1)) void conv_gemm4d_k
                 }
                 if constexpr (PROLOGUE && NVALU / NJ == 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                 if constexpr (PROLOGUE && NVALU / NJ == 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                if constexpr (RMW && I > 0) { if (m == 1 || m == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
             }
             dma(std::integral_constant<int, 2 * I>{});
             dma(std::integral_constant<int, 2 * I + 1>{});
         });
+        if constexpr (RMW) { rmw_write(NB, 2 * MI - 2); rmw_write(NB, 2 * MI - 1); }
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -297,6 +337,7 @@ __global__ __launch_bounds__(g4d::NT, (MI * NJ <= 4 ? 2 : 1)) void conv_gemm4d_k
             constexpr int E = decltype(e_c)::value;
             if constexpr (2 * G::Q + E < G::R) req(N{}, std::integral_constant<int, 2 * G::Q + E>{}, k1);
         });
+        rmw_kt = k1;
         kstep(I1{}, B{}, kt, [&](auto) {});
         // every read of this buffer retired, tile kt + 1 landed (this wave's share; the barrier makes it everybody's)
 #if defined(METRO_DBG_G4D_NO_BARRIER)
@@ -394,17 +435,18 @@ static bool g4d_shape_ok(const MetroConvDesc& d, const ConvSplit* split) {
 bool conv_gemm4d_shape_ok(const MetroConvDesc& d, const ConvSplit* split) { return g4d_shape_ok<4, 4>(d, split); }
 // tile geometry ids: 0 = 256 x 256 (4 x 4 tiles per wave), 1 = 128 couts x 128 pixels (2 x 2, two blocks per CU), 2 = 128 couts x 256 pixels
 bool conv_gemm4d_geo_ok(const MetroConvDesc& d, const ConvSplit* split, int geo) {
-    return geo == 0 ? g4d_shape_ok<4, 4>(d, split) : geo == 1 ? g4d_shape_ok<2, 2>(d, split) : geo == 2 ? g4d_shape_ok<2, 4>(d, split) : false;
+    return geo == 0 ? g4d_shape_ok<4, 4>(d, split) : geo == 1 ? g4d_shape_ok<2, 2>(d, split) : geo == 2 ? g4d_shape_ok<2, 4>(d, split)
+           : geo == 3 ? (d.has_prologue && g4d_shape_ok<4, 4>(d, split)) : false;
 }
 
-template <int MI, int NJ>
+template <int MI, int NJ, bool INPLACE = false>
 static int g4d_launch(const MetroConvDesc& d, const ConvArgs& a, const void* in, const void* w, const float* bias, const void* ps,
                       const void* pb, const half_t* r, void* out, void* out2, hipStream_t stream) {
     using G = g4d::Geo<MI, NJ>;
     const int tiles_m = (d.c_out + G::TM - 1) / G::TM;
     const int tiles_n = (a.m_total + G::TN - 1) / G::TN;
     if (d.has_prologue) {
-        auto kern = conv_gemm4d_kernel<true, MI, NJ>;
+        auto kern = conv_gemm4d_kernel<true, MI, NJ, INPLACE>;
         constexpr int lds = G::MAIN_BYTES + g4d::PRO_BYTES;
         static PerDeviceInt done;
         if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4d<pro>")) return st;
@@ -436,11 +478,12 @@ int launch_conv_gemm4d(const MetroConvDesc& d, const void* in, const void* w, co
         a.split = split->split; a.c_out2 = split->c_out2; a.relu2 = split->relu2;
         out2 = split->out2;
     }
-    static const char* const names[3] = {"256x256", "128x128", "128x256"};
+    static const char* const names[4] = {"256x256", "128x128", "128x256", "256x256,inplace"};
     if (note_kernel("conv_gemm4d<%s%s>%s%s", names[geo], d.has_prologue ? ",pro" : "", d.has_residual ? "+res" : "", a.split > 0 ? "+pair" : ""))
         return METRO_OK;
     const half_t* r = d.has_residual ? static_cast<const half_t*>(res) : nullptr;
     if (geo == 0) return g4d_launch<4, 4>(d, a, in, w, bias, ps, pb, r, out, out2, stream);
+    if (geo == 3) return g4d_launch<4, 4, true>(d, a, in, w, bias, ps, pb, r, out, out2, stream);
     if (geo == 1) return g4d_launch<2, 2>(d, a, in, w, bias, ps, pb, r, out, out2, stream);
     return g4d_launch<2, 4>(d, a, in, w, bias, ps, pb, r, out, out2, stream);
 }

@@ -30,7 +30,7 @@ int metro_conv_f16_gemm4d_geo(const MetroConvDesc* d, const void* d_in, const vo
     METRO_CHECK_ARG(!d->has_prologue || (d_pro_scale && d_pro_shift), "conv_f16_gemm4d: prologue tensors missing");
     METRO_CHECK_ARG(!d->has_residual || d_residual, "conv_f16_gemm4d: residual tensor missing");
     METRO_CHECK_ARG(split >= 0 && split < d->c_out && (split == 0 || d_out2), "conv_f16_gemm4d: bad split %d / missing second output", split);
-    METRO_CHECK_ARG(geometry >= 0 && geometry <= 2, "conv_f16_gemm4d: tile geometry %d (0 = 256 x 256, 1 = 128 x 128, 2 = 128 couts x 256 pixels)", geometry);
+    METRO_CHECK_ARG(geometry >= 0 && geometry <= 3, "conv_f16_gemm4d: tile geometry %d (0 = 256 x 256, 1 = 128 x 128, 2 = 128 couts x 256 pixels, 3 = 256 x 256 with the pre-activation in place)", geometry);
     ConvSplit sp;
     sp.split = split; sp.c_out2 = d->c_out - split; sp.relu2 = 1; sp.out2 = d_out2;
     return launch_conv_gemm4d(*d, d_in, d_w, d_bias, d_pro_scale, d_pro_shift, d_residual, d_out,

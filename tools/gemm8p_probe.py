@@ -33,8 +33,11 @@ for c_in, c_out in SHAPES:
         a4 = lib.metro_conv_f16_gemm4w(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(o4), 0, None, C.c_void_p(0))
         od = torch.empty_like(out)
         ad = xlib.metro_conv_f16_gemm4d(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None, H.ptr(sh) if pro else None, None, H.ptr(od), 0, None, C.c_void_p(0))
+        op = torch.empty_like(out)
+        ap = xlib.metro_conv_f16_gemm4d_geo(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc), H.ptr(sh), None, H.ptr(op), 0, None, 3, C.c_void_p(0)) if pro else 0
         torch.cuda.synchronize()
-        print('   bits equal to gemm8p:', a8, a4, ad, bool(torch.equal(o8, o4)), bool(torch.equal(o8, od)), float((o8.float() - od.float()).abs().max()))
+        print('   bits equal to gemm8p:', a8, a4, ad, ap, bool(torch.equal(o8, o4)), bool(torch.equal(o8, od)), float((o8.float() - od.float()).abs().max()),
+              'in-place form:', bool(torch.equal(o8, op)) if pro else None, float((o8.float() - op.float()).abs().max()) if pro else None)
         res = {}
         for name, fn in (('gemm8p', lambda: xlib.metro_conv_f16_gemm8p(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
                                                                      H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
@@ -42,8 +45,12 @@ for c_in, c_out in SHAPES:
                                                                      H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
                          ('gemm4d', lambda: xlib.metro_conv_f16_gemm4d(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc) if pro else None,
                                                                      H.ptr(sh) if pro else None, None, H.ptr(out), 0, None, C.c_void_p(0))),
+                         ('gemm4p', (lambda: xlib.metro_conv_f16_gemm4d_geo(C.byref(d), H.ptr(x), H.ptr(w), H.ptr(b), H.ptr(sc), H.ptr(sh), None,
+                                                                                     H.ptr(out), 0, None, 3, C.c_void_p(0))) if pro else None),
                          ('hipblaslt', lambda: (torch.mm(x.view(-1, c_in), w.t(), out=out.view(-1, c_out)), 0)[1]),
                          ):
+            if fn is None:
+                continue
             for _ in range(3):
                 assert fn() == 0, lib.metro_last_error()
             torch.cuda.synchronize()
