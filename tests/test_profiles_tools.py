@@ -46,3 +46,15 @@ def test_floors_of_the_default_table_use_batch64_flops():
         pytest.skip('no committed batch-64 table')
     _, total, _ = _run(tables[-1])
     assert abs(float(total[2]) - 15.299 * 64) < 1.0, total
+
+
+@pytest.mark.parametrize('name', ['knockouts_r02_r04.patch', 'knockouts_r05.patch'])
+def test_knockout_patches_still_apply(name):
+    """The timing knock-outs (#ifdef METRO_DBG_*) live OUTSIDE the product kernels, as patches (tools/build_dbg_variants.sh): they
+    must keep applying to the sources they instrument, or the knock-out tables of NOTES_dead_ends.md stop being reproducible."""
+    import shutil
+    if shutil.which('patch') is None:
+        pytest.skip('no patch(1) in this image')
+    r = subprocess.run(['patch', '-p0', '--dry-run', '-i', os.path.join('tools', name)], capture_output=True, text=True, cwd=ROOT, timeout=60)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'METRO_DBG' not in ''.join(open(f).read() for f in glob.glob(os.path.join(ROOT, 'metro_pose3d_amd', 'csrc', '*.hip')))
