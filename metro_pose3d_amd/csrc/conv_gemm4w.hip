@@ -48,7 +48,7 @@ template <bool PROLOGUE>
 __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w, const float* __restrict__ bias,
     const half_t* __restrict__ pro_scale, const half_t* __restrict__ pro_shift, const half_t* __restrict__ residual,
-    half_t* __restrict__ out, half_t* __restrict__ out2, int tiles_m) {
+    half_t* __restrict__ out, half_t* __restrict__ out2, int tiles_m, int mgroups) {
     using namespace g4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -66,8 +66,18 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
         const int xcd = b & 7, idx = b >> 3;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = lid / tiles_m;
-    const int tile_m = lid % tiles_m;
+    int tile_n = lid / tiles_m;
+    int tile_m = lid % tiles_m;
+    if (mgroups > 1) {
+        // wide outputs (block4's shortcut + conv1 pair: ten cout tiles = 5.2 MB of weights, more than an XCD's 4 MB L2): XCD x
+        // owns cout-tile group x % mgroups and pixel-tile set x / mgroups, so its weight working set is 1 / mgroups of the
+        // layer and stays L2-resident while each pixel tile is fetched by mgroups XCDs instead of one (host checks divisibility)
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int tmg = tiles_m / mgroups, sets = 8 / mgroups;
+        const int tns = (nblk / tiles_m) / sets;
+        tile_m = (xcd % mgroups) * tmg + idx % tmg;
+        tile_n = (xcd / mgroups) * tns + idx / tmg;
+    }
     const int m0 = tile_n * TN;
     const int n0 = tile_m * TM;
     const int K = a.c_in;
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     // no shortcut to add (every layer this kernel is dispatched for) and a whole 256-channel tile: the chunk reads of eight
     // iterations back to back, then eight full-line stores.  The general loop below carries a per-lane guard and the shortcut
     // branches in every iteration -- hipcc emits read - wait - store 32 times in a row (~2.5 us per 256 x 256 tile).
-    if (residual == nullptr && o_n0 + TM <= o_c) {
+    if (residual == nullptr && o_n0 + TM <= o_c && m0 + TN <= a.m_total) {     // block-uniform; m % 256 == 0 is also a host-side precondition
         const int ch = tid & (CPRO - 1), pr0 = tid / CPRO;         // NT % CPRO == 0: a lane keeps its chunk column
 #pragma unroll
         for (int it0 = 0; it0 < EPI_ITERS; it0 += 8) {
@@ -331,8 +341,9 @@ bool conv_gemm4w_shape_ok(const MetroConvDesc& d, const ConvSplit* split) {
 // batch 64: 44 vs 41 us), at four tiles per CU it wins (batch 256: 125 vs 134 us).
 bool conv_gemm4w_supported(const MetroConvDesc& d, const ConvSplit* split) {
     static const int enabled = tuning_knob("METRO_GEMM4W", 1);
-    static const int min_tiles = tuning_knob("METRO_GEMM8P_MIN_TILES", 256);
-    static const int min_k = tuning_knob("METRO_GEMM8P_MIN_K", 512);
+    // (the knobs were named METRO_GEMM8P_* after the round-2 kernel this one replaced; the old names stay as aliases)
+    static const int min_tiles = tuning_knob("METRO_GEMM4W_MIN_TILES", tuning_knob("METRO_GEMM8P_MIN_TILES", 256));
+    static const int min_k = tuning_knob("METRO_GEMM4W_MIN_K", tuning_knob("METRO_GEMM8P_MIN_K", 512));
     if (!enabled || !d.has_prologue || !conv_gemm4w_shape_ok(d, split) || d.c_in < min_k) return false;
     const long m = (long)d.n * d.h_out * d.w_out;
     const long tiles = (long)(d.c_out / 256) * (m / 256);
@@ -356,6 +367,13 @@ int launch_conv_gemm4w(const MetroConvDesc& d, const void* in, const void* w, co
         return METRO_OK;
     const int tiles_m = (d.c_out + g4::TM - 1) / g4::TM;
     const int tiles_n = (a.m_total + g4::TN - 1) / g4::TN;
+    // cout-tile groups per XCD set (kernel comment): only where the layer's weights exceed an XCD's L2
+    static const int mg_knob = tuning_knob("METRO_G4_MGROUPS", 1);
+    static const int mg_min_w = tuning_knob("METRO_G4_MGROUPS_MIN_WBYTES", 4 << 20);
+    int mgroups = 1;
+    if (mg_knob > 1 && (long)d.c_out * d.c_in * 2 > mg_min_w && 8 % mg_knob == 0 && tiles_m % mg_knob == 0 &&
+        tiles_n % (8 / mg_knob) == 0)
+        mgroups = mg_knob;
     const half_t* r = d.has_residual ? static_cast<const half_t*>(res) : nullptr;
     if (d.has_prologue) {
         auto kern = conv_gemm4w_kernel<true>;
@@ -364,7 +382,7 @@ int launch_conv_gemm4w(const MetroConvDesc& d, const void* in, const void* w, co
         if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4w<pro>")) return st;
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(g4::NT), lds, stream, a, static_cast<const half_t*>(in),
                            static_cast<const half_t*>(w), bias, static_cast<const half_t*>(ps), static_cast<const half_t*>(pb), r,
-                           static_cast<half_t*>(out), static_cast<half_t*>(out2), tiles_m);
+                           static_cast<half_t*>(out), static_cast<half_t*>(out2), tiles_m, mgroups);
     } else {
         auto kern = conv_gemm4w_kernel<false>;
         constexpr int lds = g4::MAIN_BYTES;
@@ -372,7 +390,7 @@ int launch_conv_gemm4w(const MetroConvDesc& d, const void* in, const void* w, co
         if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4w")) return st;
         hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(g4::NT), lds, stream, a, static_cast<const half_t*>(in),
                            static_cast<const half_t*>(w), bias, nullptr, nullptr, r, static_cast<half_t*>(out),
-                           static_cast<half_t*>(out2), tiles_m);
+                           static_cast<half_t*>(out2), tiles_m, mgroups);
     }
     return launch_status("conv_gemm4w");
 }

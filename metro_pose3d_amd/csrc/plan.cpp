@@ -591,7 +591,10 @@ int build_plan(MetroPlan* p) {
                 probe.n = 1;
                 // block2 (128 -> 512 on 32-wide maps): the persistent kernel with all 512 channels of a pixel tile in one block
                 const bool pw_next = probe.c_in == 128 && cb == 128 && conv_pw64_supported(probe, 2);
-                if (conv_f16_fuse2_supported(probe, cb) || unit_fused || pw_next) {
+                // chain_mid: unit 2 of block1's rebuild chain has no residual tensor to read -- its identity shortcut exists only
+                // inside the fused conv3 + next-conv1 launch (conv_pw64 REB), so the fusion is not optional there (METRO_FUSE2=0
+                // used to drop the shortcut silently: ADVICE r5)
+                if (conv_f16_fuse2_supported(probe, cb) || unit_fused || chain_mid || pw_next) {
                     const std::string un2 = "block" + std::to_string(b + 1) + "/unit_" + std::to_string(u + 1);
                     B.fuse_next_conv1(un2, un2 + "/bottleneck_v2", side_out, cout, cb);
                     conv1_done = true;
@@ -747,6 +750,11 @@ int launch_layer(const MetroPlan* p, const char* d_params, int li, const float* 
                 return launch_conv_f16_dma(cd, slot_ptr(L.in_slot), prm(L.p_w), static_cast<const float*>(prm(L.p_bias)),
                                            nullptr, nullptr, slot_ptr(L.res_slot), slot_ptr(L.out_slot), stream, nullptr, &f2,
                                            L.psc_w >= 0 ? &ps : nullptr, has_rb ? &rb : nullptr);
+            }
+            if (L.reb_w >= 0 || L.out_mode != 0) {
+                // only the fused conv3 + next-conv1 launch above reads the rebuild data; any other path would drop the shortcut
+                set_error("internal: layer %d carries block1 rebuild data (reb_w %d, out_mode %d) but no fused next-conv1 launch", li, L.reb_w, L.out_mode);
+                return METRO_ERR_STATE;
             }
             if (p->fast && L.p1_w >= 0) {
                 ConvPre1 p1;

@@ -10,8 +10,10 @@ mode that is always the case (one kernel configuration whatever the batch: tests
 test_f64_mode_is_shard_invariant).  In the `f16` throughput mode tile shapes follow the crops per call (thresholds: 128 crops
 at stride 16, 32 at stride 8, 8 at stride 4 -- see inference.estimate_pose), so a shard below a threshold and a full batch above
 it differ by fp16 rounding flips; below the thresholds the bits are the same.
-A failure on ONE rank (fp16 overflow on its shard, a HIP error) is made collective: the rank still joins the gather and its
-status row tells every rank to raise (all_gather_poses_with_status) -- nobody is left blocking in the collective.
+A failure on ONE rank -- fp16 overflow on its shard, or an exception in its model load / plan build / upload / forward -- is
+made collective: the rank still joins the gather and its status row tells every rank to raise (all_gather_poses_with_status),
+so nobody is left blocking in the collective.  Not covered: a rank that cannot allocate a device tensor any more (sticky HIP
+error under `nccl`) -- the process group's timeout ends the others (inference.estimate_pose lists the cases).
 (The reference has no multi-GPU code at all; this is defined by BASELINE.json's north star.)
 """
 from __future__ import annotations
@@ -63,6 +65,10 @@ def all_gather_poses_with_status(local: torch.Tensor, n_total: int, status: int,
     status of every rank) so that all ranks can raise together instead of leaving the healthy ones blocked in the gather."""
     world = dist.get_world_size(group)
     j, c = local.shape[1], local.shape[2]
+    # the status rides as a float in element [q, 0, 0]: exact only in fp32 and only for |status| < 2**24 (saturated below)
+    if local.dtype != torch.float32 or j < 1 or c < 1:
+        raise ValueError(f'all_gather_poses_with_status: poses must be float32 [n, J >= 1, 3], got {local.dtype} {tuple(local.shape)}')
+    status = max(-1, min(int(status), (1 << 24) - 1))
     q = -(-n_total // world)
     padded = torch.zeros((q + 1, j, c), dtype=local.dtype, device=local.device)
     padded[:local.shape[0]] = local

@@ -64,6 +64,10 @@ def _engine_for(model_path: str, precision: str, device: torch.device, n: int = 
     return eng
 
 
+class _ShapeError(ValueError):
+    """Wrong image shape: raised identically on every rank of a sharded call, before any collective."""
+
+
 def clear_cache() -> None:
     """Closes every cached engine (plan, parameter blob, workspace: 2.6 GB at bucket 256) after draining its device."""
     while _ENGINES:
@@ -134,20 +138,25 @@ def estimate_pose(images_tensor, model_path, precision: Optional[str] = None, ch
             raise _lib.MetroError('shard=True needs an initialised torch.distributed process group with more than one rank')
     from metro_pose3d_amd.dist import shard_range
     begin, end = shard_range(n, rank, world) if n else (0, 0)
-    eng = _engine_for(model_path, precision, device, max(end - begin, 1))
-    s = eng.spec.proc_side
-    if images_tensor.dim() != 4 or tuple(images_tensor.shape[1:]) != (s, s, 3):
-        raise ValueError(f'images must be NHWC [N,{s},{s},3] (reference main.py:109-110), got '
-                         f'{tuple(images_tensor.shape)}')
-    images = images_tensor[begin:end].to(device, non_blocking=True).contiguous()      # only this rank's shard goes to its GPU
-    sk = eng.spec.skeleton
-    poses = torch.empty((end - begin, sk.n_out, 3), dtype=torch.float32, device=device)
     # Per-rank failures must not leave the other ranks blocked in the gather: a failing rank records its error, STILL joins the
     # collective (its status row says so) and every rank raises afterwards.  Status: 0 fine, k > 0 = k crops of this rank's
-    # shard reached the soft-argmax non-finite (fp16 overflow), -1 = the forward itself raised.
-    status, err = 0, None
+    # shard reached the soft-argmax non-finite (fp16 overflow), -1 = this rank raised -- in the model load, the plan build, the
+    # workspace allocation, the shard upload or the forward loop (all inside the try since round 6).
+    # What is NOT covered: a failure that leaves this rank unable to take part in a collective at all -- the model file cannot be
+    # read far enough to learn the output joint count (every rank passes the same path: they then all raise here, before any
+    # collective), a wrong image shape (ValueError on every rank alike), or a sticky HIP error after which no device tensor can
+    # be allocated under backend `nccl` (the process group's own timeout ends the other ranks).
+    status, err, eng, poses, n_out = 0, None, None, None, None
     with (torch.cuda.device(device) if device.type == 'cuda' else contextlib.nullcontext()):
         try:
+            eng = _engine_for(model_path, precision, device, max(end - begin, 1))
+            s = eng.spec.proc_side
+            n_out = eng.spec.skeleton.n_out
+            if images_tensor.dim() != 4 or tuple(images_tensor.shape[1:]) != (s, s, 3):
+                raise _ShapeError(f'images must be NHWC [N,{s},{s},3] (reference main.py:109-110), got '
+                                  f'{tuple(images_tensor.shape)}')
+            images = images_tensor[begin:end].to(device, non_blocking=True).contiguous()      # only this rank's shard goes to its GPU
+            poses = torch.empty((end - begin, n_out, 3), dtype=torch.float32, device=device)
             bad = None
             for i in range(0, end - begin, eng.max_batch):
                 k = min(eng.max_batch, end - begin - i)
@@ -157,10 +166,18 @@ def estimate_pose(images_tensor, model_path, precision: Optional[str] = None, ch
                     bad = cnt if bad is None else bad + cnt
             if bad is not None:
                 status = int(bad.item())                                 # the call's one stream synchronisation
+        except _ShapeError:
+            raise                       # the same on every rank (same images): no collective was entered by anybody
         except Exception as e:          # noqa: BLE001 -- re-raised below, after the collective
             status, err = -1, e
         if world > 1:
             try:
+                if err is not None:
+                    # join with a FRESH tensor that only carries the status row: `poses` may be unallocated or hold garbage
+                    if n_out is None:
+                        n_out = load_model(model_path)[0].skeleton.n_out       # raises if the file is unreadable (every rank alike)
+                    on_host = torch.distributed.get_backend(group) != 'nccl'
+                    poses = torch.zeros((end - begin, n_out, 3), dtype=torch.float32, device='cpu' if on_host else device)
                 poses, statuses = _gather_shards(poses, n, group, status)
             except Exception:
                 if err is not None:
@@ -177,6 +194,7 @@ def estimate_pose(images_tensor, model_path, precision: Optional[str] = None, ch
         raise _lib.NonFiniteError(
             f'{eng.spec.arch_name} stride {eng.spec.stride} in precision {precision!r}: crops reached the soft-argmax with non-finite '
             f'statistics ({failed})' + (' (fp16 storage overflows at 65504: run this model with precision f32m or f64)' if precision == 'f16' else ''))
+    sk = eng.spec.skeleton
     names = np.empty(sk.n_out, dtype=object)
     names[:] = sk.names_bytes()
     return poses, sk.edges_array(), names

@@ -32,11 +32,18 @@ def test_floors_of_the_batch256_table_use_batch256_flops():
     # RN50-s16-J17: 15.299 GFLOP per crop x 256 crops (metro_plan_flops_per_image), whatever the launch set looks like
     assert abs(float(total[2]) - 15.299 * 256) < 2.0, total
     assert 'sum of per-launch floors' in out
-    frac = float(total[7])
+    # columns: layer us GFLOP algo_MB counter_MB counter/algo mfma_floor hbm_floor floor floor/measured bound
+    frac = float(total[9])
     assert 0.3 < frac < 1.0, total
+    # the default takes the HBM floor from ALGORITHMIC bytes (measured bytes flatter the score) and the
+    # last line prints both sums; --measured-bytes can only raise it (counter bytes >= algorithmic bytes, launch by launch)
+    assert 'floors from ALGORITHMIC bytes' in out and '# both: with algorithmic bytes' in out
+    assert float(total[4]) >= float(total[3]) > 0, total
+    _, total_m, out_m = _run(table, '--measured-bytes')
+    assert 'floors from MEASURED' in out_m and float(total_m[9]) >= frac
     # the measured ceilings can only raise the ratio
     _, total2, _ = _run(table, '--mfma-tflops', '1700', '--hbm-gbs', '4500')
-    assert float(total2[7]) > frac
+    assert float(total2[9]) > frac
 
 
 def test_floors_of_the_default_table_use_batch64_flops():

@@ -73,6 +73,73 @@ __global__ __launch_bounds__(512) void mfma_loop_kernel(const half8_t* __restric
     if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = w1 - w0; }
 }
 
+// Round 6: the same loop on other instruction forms -- does any of them hold a higher clock on the data the
+// net multiplies?  VARIANT 1: v_mfma_f32_16x16x32_f16 (what hipBLASLt's kernels issue; half the work per instruction, 16
+// accumulators of 4 registers); 2: 32x32x16 with the accumulators pinned in AGPRs (inline asm, "a" constraint: the matrix
+// pipe then reads and writes the accumulator file instead of the architected VGPRs); 3: 16x16x32 with AGPR accumulators.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int VARIANT>
+__global__ __launch_bounds__(512) void mfma_loop_variant_kernel(const half8_t* __restrict__ frags, float* __restrict__ sink, int iters,
+                                                                unsigned long long* __restrict__ clocks) {
+    const int lane = threadIdx.x & 63;
+    half8_t a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = frags[(i * 64 + lane)];
+        b[i] = frags[((8 + i) * 64 + lane)];
+    }
+    constexpr bool SMALL = VARIANT == 1 || VARIANT == 3;       // 16x16x32: 16 accumulators x 4 registers
+    constexpr bool AGPR = VARIANT == 2 || VARIANT == 3;
+    floatx16 acc[8];
+    floatx4 acs[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acs[t][e] = 0.f;
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    const unsigned long long w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if constexpr (!SMALL) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if constexpr (AGPR)
+                        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(a[(t + r) & 7]), "v"(b[(t * 3 + r * 5) & 7]));
+                    else
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(t + r) & 7], b[(t * 3 + r * 5) & 7], acc[t], 0, 0, 0);
+                }
+            } else {
+                // 16 MFMAs of 16x16x32 = the FLOPs of 8 MFMAs of 32x32x16
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    if constexpr (AGPR)
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acs[t]) : "v"(a[(t + r) & 7]), "v"(b[(t * 3 + r * 5) & 7]));
+                    else
+                        acs[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(t + r) & 7], b[(t * 3 + r * 5) & 7], acs[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    const unsigned long long w1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[t][e];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += acs[t][e];
+    if (s == 123.456f) sink[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = w1 - w0; }
+}
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void hbm_read_kernel(const u32x4* __restrict__ src, size_t n16, u32x4* __restrict__ sink) {
@@ -112,8 +179,31 @@ extern "C" {
 
 const char* metro_probe_last_error(void) { return g_probe_err; }
 
+static int probe_mfma(int kind, int variant, double min_ms, double* tflops_out, double* sclk_mhz_out, double* ms_out);
+
 int metro_probe_mfma_f16(int kind, double min_ms, double* tflops_out, double* sclk_mhz_out, double* ms_out) {
-    if (kind < 0 || kind > 2 || !tflops_out) { snprintf(g_probe_err, sizeof(g_probe_err), "bad argument"); return -1; }
+    return probe_mfma(kind, 0, min_ms, tflops_out, sclk_mhz_out, ms_out);
+}
+
+// variant 0: v_mfma_f32_32x32x16_f16 (= metro_probe_mfma_f16); 1: v_mfma_f32_16x16x32_f16; 2: 32x32x16 with AGPR accumulators;
+// 3: 16x16x32 with AGPR accumulators
+int metro_probe_mfma_f16_variant(int kind, int variant, double min_ms, double* tflops_out, double* sclk_mhz_out, double* ms_out) {
+    return probe_mfma(kind, variant, min_ms, tflops_out, sclk_mhz_out, ms_out);
+}
+
+}  // extern "C"
+
+static void launch_mfma_loop(int variant, int grid, const half8_t* frags, float* sink, int iters, unsigned long long* clk) {
+    switch (variant) {
+        case 1: hipLaunchKernelGGL(mfma_loop_variant_kernel<1>, dim3(grid), dim3(512), 0, 0, frags, sink, iters, clk); break;
+        case 2: hipLaunchKernelGGL(mfma_loop_variant_kernel<2>, dim3(grid), dim3(512), 0, 0, frags, sink, iters, clk); break;
+        case 3: hipLaunchKernelGGL(mfma_loop_variant_kernel<3>, dim3(grid), dim3(512), 0, 0, frags, sink, iters, clk); break;
+        default: hipLaunchKernelGGL(mfma_loop_kernel, dim3(grid), dim3(512), 0, 0, frags, sink, iters, clk);
+    }
+}
+
+static int probe_mfma(int kind, int variant, double min_ms, double* tflops_out, double* sclk_mhz_out, double* ms_out) {
+    if (kind < 0 || kind > 2 || variant < 0 || variant > 3 || !tflops_out) { snprintf(g_probe_err, sizeof(g_probe_err), "bad argument"); return -1; }
     const int nfrag = 16 * 64;
     std::vector<_Float16> host((size_t)nfrag * 8);
     uint64_t seed = 0x9e3779b97f4a7c15ull + (uint64_t)kind;
@@ -138,9 +228,9 @@ int metro_probe_mfma_f16(int kind, double min_ms, double* tflops_out, double* sc
     int iters = 2000;
     float ms = 0.f;
     for (int attempt = 0; attempt < 6; ++attempt) {
-        hipLaunchKernelGGL(mfma_loop_kernel, dim3(grid), dim3(512), 0, 0, d_frags, d_sink, iters / 4, d_clk);   // warm-up
+        launch_mfma_loop(variant, grid, d_frags, d_sink, iters / 4, d_clk);   // warm-up
         PROBE_CHECK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(mfma_loop_kernel, dim3(grid), dim3(512), 0, 0, d_frags, d_sink, iters, d_clk);
+        launch_mfma_loop(variant, grid, d_frags, d_sink, iters, d_clk);
         PROBE_CHECK(hipEventRecord(e1, 0));
         PROBE_CHECK(hipEventSynchronize(e1));
         PROBE_CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -157,6 +247,8 @@ int metro_probe_mfma_f16(int kind, double min_ms, double* tflops_out, double* sc
     (void)hipFree(d_frags); (void)hipFree(d_sink); (void)hipFree(d_clk);
     return 0;
 }
+
+extern "C" {
 
 int metro_probe_hbm(int kind, int64_t bytes, double* tb_per_s_out, double* us_out) {
     if (kind < 0 || kind > 1 || bytes < (1 << 20) || !tb_per_s_out) { snprintf(g_probe_err, sizeof(g_probe_err), "bad argument"); return -1; }
