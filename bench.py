@@ -82,6 +82,16 @@ def measured_peaks():
             rec[name] = {'error': lib.metro_probe_last_error().decode()}
             continue
         rec[name] = {'tflops': round(tf.value, 1), 'sclk_mhz': round(mhz.value), 'ms': round(ms.value, 2)}
+    # round 6: the same loop on the other instruction forms, on the operands the net multiplies (relu x He): a register-resident
+    # 16x16x32 loop holds a higher clock -- inside the real kernels both forms measured SLOWER (NOTES_dead_ends.md, Round 6)
+    if hasattr(lib, 'metro_probe_mfma_f16_variant'):
+        lib.metro_probe_mfma_f16_variant.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        for variant, name in ((1, 'mfma_f16_16x16x32_relu_x_he'), (2, 'mfma_f16_32x32x16_agpr_acc_relu_x_he'), (3, 'mfma_f16_16x16x32_agpr_acc_relu_x_he')):
+            tf, mhz, ms = C.c_double(), C.c_double(), C.c_double()
+            if lib.metro_probe_mfma_f16_variant(2, variant, 2.0, C.byref(tf), C.byref(mhz), C.byref(ms)) != 0:
+                rec[name] = {'error': lib.metro_probe_last_error().decode()}
+                continue
+            rec[name] = {'tflops': round(tf.value, 1), 'sclk_mhz': round(mhz.value), 'ms': round(ms.value, 2)}
     for kind, name in ((0, 'hbm_read'), (1, 'hbm_copy')):
         for size, tag in ((1 << 30, '_1GiB'), (64 << 20, '_64MiB')):
             tb, us = C.c_double(), C.c_double()
@@ -104,7 +114,8 @@ def peak_measured_for(bound: str):
         return {'error': pk['error']}
     if bound == 'mfma':
         # the forward is MFMA-bound in some launches and HBM-bound in others: both measured ceilings travel with its fraction
-        return ({k: pk[k] for k in ('mfma_f16_random', 'mfma_f16_relu_x_he', 'mfma_f16_zeros') if k in pk} | {'unit': 'TFLOP/s'} |
+        return ({k: pk[k] for k in ('mfma_f16_random', 'mfma_f16_relu_x_he', 'mfma_f16_zeros', 'mfma_f16_16x16x32_relu_x_he',
+                                    'mfma_f16_32x32x16_agpr_acc_relu_x_he', 'mfma_f16_16x16x32_agpr_acc_relu_x_he') if k in pk} | {'unit': 'TFLOP/s'} |
                 {'hbm': {k: pk[k] for k in ('hbm_read_1GiB', 'hbm_copy_1GiB', 'hbm_read_64MiB', 'hbm_copy_64MiB') if k in pk} | {'unit': 'GB/s'},
                  'source': pk['source']})
     return {k: pk[k] for k in ('hbm_read_1GiB', 'hbm_copy_1GiB', 'hbm_read_64MiB', 'hbm_copy_64MiB') if k in pk} | {'unit': 'GB/s', 'source': pk['source']}

@@ -275,7 +275,10 @@ int  metro_conv_f16_next_rebuild(const MetroConvDesc* d, const void* d_in, const
  * instead (what metro_forward_upto stopping at such a layer runs): two independent forms that must give the same bits.
  * It also switches metro_conv_f16 between conv_pws.hip's skewed kernel (default; conv3 + shortcut of blocks 3-4) and
  * conv_pw64.hip's lock-step one (1), and metro_conv_f16_pair on block2's shapes (256 -> 512 + 128) between the weight-resident
- * kernel conv_pw64<k256,wm8,cb512,pro,pair> (default, round 5) and the ring kernel it replaced (1): again the same bits. */
+ * kernel conv_pw64<k256,wm8,cb512,pro,pair> (default, round 5) and the ring kernel it replaced (1): again the same bits.
+ * Round 6: and the dilated 3x3 layers whose halo exceeds the tap-reuse kernel's slab (rate 4 / 8 at stride 4 and 8) between that
+ * kernel in sub-grid pixel order ("conv3x3_f16_slab<...>+subgrid", default) and the generic ring kernel (1): two fp32 summation
+ * orders of the same products (chunk-major / tap-major), equal up to rounding flips of the fp16 result. */
 int  metro_conv_b1_form(int32_t classic);
 /* The same contract as metro_conv_f16 / metro_conv_f16_pair on the 256 x 256 x 64 GEMM kernel with four waves of 128 x 128
  * (conv_gemm4w.hip: register-staged operands, one barrier per K tile), which metro_forward picks for the pre-activated deep-K

@@ -108,7 +108,7 @@ __device__ __forceinline__ void slab_static_for(F&& f) {
 template <class Cfg>
 __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __restrict__ in, const half_t* __restrict__ w,
                                           const float* __restrict__ bias, half_t* __restrict__ out, int halo, int m0, int n0,
-                                          char* smem, int tid) {
+                                          char* smem, int tid, int sgd) {
     constexpr int NW = Cfg::NW;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,7 +118,25 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
     const int c_in = a.c_in;
     const int k_total = 9 * c_in;
     const int kc = c_in / Cfg::KC;                 // chunks (c_in % 64 == 0: launcher)
-    const int hw = a.h_out * a.w_out;
+    // SUB-GRID mode (sgd = the layer's rate d > 1, round 6).  A rate-d 3x3 convolution with SAME padding on an H x W map is d*d
+    // independent rate-1 convolutions on the (H/d) x (W/d) sub-images of the pixels with equal (y mod d, x mod d): a tap of
+    // pixel (y, x) lands on (y +- d, x +- d), the same residue class, and leaves the image exactly when it leaves the sub-image.
+    // The tile walks the pixels in SUB-IMAGE order -- virtual image n*d*d + (y mod d)*d + (x mod d), row y / d, column x / d -- so
+    // its slab needs W/d rows of halo instead of d*W (rate 8 on a 64-wide map: 8 instead of 512: such layers used to fall to the
+    // generic ring kernel, which re-fetches the activations for every tap); only the two places that turn a pixel index
+    // into an address (the slab's DMA sources, the output rows) know about the permutation.  The k order is this kernel's
+    // (chunk-major: every tap of a channel chunk, then the next chunk), as for every other layer it serves.
+    const int gw = sgd ? a.w_out / sgd : a.w_out, gh = sgd ? a.h_out / sgd : a.h_out, gdil = sgd ? 1 : a.dil;
+    const int hw = gh * gw;
+    auto pixel_of = [&](int g) -> size_t {         // virtual (tile-order) pixel index -> NHWC pixel index
+        if (!sgd) return (size_t)g;
+        const int vimg = g / hw, rem = g - vimg * hw;
+        const int vy = rem / gw, vx = rem - vy * gw;
+        const int d2 = sgd * sgd;
+        const int img = vimg / d2, sub = vimg - img * d2;
+        const int sy = sub / sgd, sx = sub - sy * sgd;
+        return ((size_t)img * a.h_out + (vy * sgd + sy)) * a.w_out + (vx * sgd + sx);
+    };
     const half_t* zero = reinterpret_cast<const half_t*>(g_zero_page_slab);
     const unsigned smem_base = (unsigned)(size_t)(lds_void3_t*)smem;
 
@@ -136,8 +154,9 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
     for (int i = 0; i < Cfg::SI; ++i) {
         const int srow = (i * NW + wave) * RPI + lrow;
         const int g = m0 - halo + srow;              // flattened pixel index
-        svalid[i] = g >= 0 && g < a.m_total;
-        ssrc[i] = in + (size_t)(svalid[i] ? g : 0) * c_in;
+        // rows past the tile's own halo (a configuration's slab is sized for the largest halo it serves) come from the zero page
+        svalid[i] = g >= 0 && g < a.m_total && srow < Cfg::TN + 2 * halo;
+        ssrc[i] = in + pixel_of(svalid[i] ? g : 0) * c_in;
         skoff[i] = (lch ^ Cfg::swz(srow)) * 8;
     }
     const half_t* wsrc[Cfg::WI];
@@ -201,15 +220,15 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
         const int t = (wave_n * Cfg::WN + j) * 32 + frag_row;        // tile-local pixel
         const int m = m0 + t;
         const int rem = m % hw;
-        const int h = rem / a.w_out, x = rem - h * a.w_out;
+        const int h = rem / gw, x = rem - h * gw;
         bbase[j] = (halo + t) * Cfg::ROW_BYTES;
         bmask[j] = 0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int dr = (tap / 3 - 1) * a.dil, ds = (tap % 3 - 1) * a.dil;
-            const bool ok = m < a.m_total && (unsigned)(h + dr) < (unsigned)a.h_out &&
-                            (unsigned)(x + ds) < (unsigned)a.w_out;
-            if constexpr (TABLE) boff[j][tap] = ok ? (halo + t + dr * a.w_out + ds) * Cfg::ROW_BYTES : -1;
+            const int dr = (tap / 3 - 1) * gdil, ds = (tap % 3 - 1) * gdil;
+            const bool ok = m < a.m_total && (unsigned)(h + dr) < (unsigned)gh &&
+                            (unsigned)(x + ds) < (unsigned)gw;
+            if constexpr (TABLE) boff[j][tap] = ok ? (halo + t + dr * gw + ds) * Cfg::ROW_BYTES : -1;
             bmask[j] |= ok ? 1u << tap : 0u;
         }
     }
@@ -255,7 +274,7 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
                 bo = boff[j][TAP];
                 ok = bo >= 0;
             } else {
-                const int toff = __builtin_amdgcn_readfirstlane((((TAP / 3 - 1) * a.w_out + (TAP % 3 - 1)) * a.dil) * Cfg::ROW_BYTES);
+                const int toff = __builtin_amdgcn_readfirstlane((((TAP / 3 - 1) * gw + (TAP % 3 - 1)) * gdil) * Cfg::ROW_BYTES);
                 bo = bbase[j] + toff;
                 ok = (bmask[j] >> TAP) & 1u;
             }
@@ -358,13 +377,14 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
         const int co = n0 + ch * 8;
         if (m >= a.m_total || co >= a.c_out) continue;
         const uint4 v = *reinterpret_cast<const uint4*>(smem + prow * Cfg::OUT_ROW_BYTES + ch * 16);
+        const size_t mo = pixel_of(m);
         if (co + 8 <= a.c_out) {
-            store_out16<2>(out + (size_t)m * a.c_out + co, v);
+            store_out16<2>(out + mo * a.c_out + co, v);
         } else {
             const half8_t x = *reinterpret_cast<const half8_t*>(&v);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (co + e < a.c_out) out[(size_t)m * a.c_out + co + e] = x[e];
+                if (co + e < a.c_out) out[mo * a.c_out + co + e] = x[e];
         }
     }
 }
@@ -372,7 +392,7 @@ __device__ __forceinline__ void slab_tile(const ConvArgs& a, const half_t* __res
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
     ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w,
-    const float* __restrict__ bias, half_t* __restrict__ out, int tiles_m, int halo) {
+    const float* __restrict__ bias, half_t* __restrict__ out, int tiles_m, int halo, int sgd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nblk = gridDim.x;
     int lid;
@@ -384,14 +404,14 @@ __global__ __launch_bounds__(Cfg::NT) void conv3x3_f16_slab_kernel(
     }
     const int tile_n = lid / tiles_m;
     const int tile_m = lid % tiles_m;
-    slab_tile<Cfg>(a, in, w, bias, out, halo, tile_n * Cfg::TN, tile_m * Cfg::TM, smem, threadIdx.x);
+    slab_tile<Cfg>(a, in, w, bias, out, halo, tile_n * Cfg::TN, tile_m * Cfg::TM, smem, threadIdx.x, sgd);
 }
 
 template <class Cfg>
 static int launch_slab_cfg(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias,
-                           half_t* out, int halo, hipStream_t stream) {
-    if (note_kernel("conv3x3_f16_slab<%dx%d,rows%d,bufs%d,tps%d,kc%d,ws%d>", Cfg::TM, Cfg::TN, Cfg::SLAB_ROWS, Cfg::SLAB_BUFS, Cfg::TPS,
-                    Cfg::KC, Cfg::W_STAGES))
+                           half_t* out, int halo, hipStream_t stream, int sgd = 0) {
+    if (note_kernel("conv3x3_f16_slab<%dx%d,rows%d,bufs%d,tps%d,kc%d,ws%d>%s", Cfg::TM, Cfg::TN, Cfg::SLAB_ROWS, Cfg::SLAB_BUFS, Cfg::TPS,
+                    Cfg::KC, Cfg::W_STAGES, sgd ? "+subgrid" : ""))
         return METRO_OK;
     auto kern = conv3x3_f16_slab_kernel<Cfg>;
     static PerDeviceInt attr_done;
@@ -399,7 +419,7 @@ static int launch_slab_cfg(const ConvArgs& a, const half_t* in, const half_t* w,
     const int tiles_m = (a.c_out + Cfg::TM - 1) / Cfg::TM;
     const int tiles_n = (a.m_total + Cfg::TN - 1) / Cfg::TN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, stream, a, in, w, bias,
-                       out, tiles_m, halo);
+                       out, tiles_m, halo, sgd);
     return launch_status("conv3x3_f16_slab");
 }
 
@@ -423,6 +443,27 @@ using Slab64r384b1 = SlabCfg<1, 8, 2, 1, 384, 1>;  // single chunk (c_in == 64),
 using Slab64r320b1 = SlabCfg<1, 8, 2, 1, 320, 1>;
 using Slab128p512 = SlabCfg<2, 4, 2, 4, 640, 2, 1, 32, METRO_SLAB_WS512>;   // 128 cout x 512 px, 32-channel chunks, halo <= 64: 80 + 32 KiB (epilogue tile 136 KiB)
 
+static bool slab_plain_ok(const MetroConvDesc& d) {
+    // tiles are 256 consecutive pixels starting at column 0 (256 % W == 0): a tap (dr, ds<0) of a pixel
+    // at x < dil is outside the image, so the slab needs dil*W rows of halo, not dil*W + dil
+    if (256 % d.w_out != 0) return false;
+    const int halo = d.dilation * d.w_out;
+    if (d.c_out <= 64) return halo <= 128;
+    return halo <= 64;   // (the 64-cout tiles used for few-tile layers allow more, kept equal for simplicity)
+}
+
+// The rate d of a layer that runs in sub-grid order (slab_tile), 0 for the plain tile order.  METRO_SLAB_SUBGRID: 0 = never,
+// 1 = where the plain order's halo (d * W rows) exceeds the slab (stride 4: rate 4 / 8 on 64-wide maps; stride 8: rate 4 on 32-wide
+// maps -- until round 6 these fell to the generic ring kernel), 2 = every dilated layer (A/B runs).
+static int slab_subgrid_rate(const MetroConvDesc& d) {
+    static const int mode = tuning_knob("METRO_SLAB_SUBGRID", 1);
+    const int r = d.dilation;
+    // (under the test switch metro_conv_b1_form(1) such layers run where they ran before round 6: the ring kernel, tap-major)
+    if (mode == 0 || classic_forms_forced() || r <= 1 || d.h_out % r != 0 || d.w_out % r != 0 || 256 % (d.w_out / r) != 0) return 0;
+    if (mode == 1 && slab_plain_ok(d)) return 0;
+    return r;
+}
+
 bool conv3x3_slab_supported(const MetroConvDesc& d) {
     static const int enabled = tuning_knob("METRO_CONV_SLAB", 1);
     if (!enabled) return false;
@@ -431,14 +472,9 @@ bool conv3x3_slab_supported(const MetroConvDesc& d) {
           d.out_dtype == METRO_F16 && d.in_dtype == METRO_F16 && d.in_pix_stride == d.c_in &&
           d.c_in % 64 == 0 && d.c_out % 8 == 0))
         return false;
-    // tiles are 256 consecutive pixels starting at column 0 (256 % W == 0): a tap (dr, ds<0) of a pixel
-    // at x < dil is outside the image, so the slab needs dil*W rows of halo, not dil*W + dil
-    if (256 % d.w_out != 0) return false;
-    const int halo = d.dilation * d.w_out;
     const long m = (long)d.n * d.h_out * d.w_out;
     if (m < 256) return false;
-    if (d.c_out <= 64) return halo <= 128;
-    return halo <= 64;   // (the 64-cout tiles used for few-tile layers allow more, kept equal for simplicity)
+    return slab_subgrid_rate(d) > 0 || slab_plain_ok(d);
 }
 
 int launch_conv3x3_slab(const MetroConvDesc& d, const void* in_, const void* w_, const float* bias,
@@ -447,25 +483,31 @@ int launch_conv3x3_slab(const MetroConvDesc& d, const void* in_, const void* w_,
     const half_t* in = static_cast<const half_t*>(in_);
     const half_t* w = static_cast<const half_t*>(w_);
     half_t* out = static_cast<half_t*>(out_);
-    const int halo = d.dilation * d.w_out;
+    const int sgd = slab_subgrid_rate(d);
+    const int halo = sgd ? d.w_out / sgd : d.dilation * d.w_out;       // sub-grid order: a rate-1 layer on (W / d)-wide sub-images
     // 64-cout tiles when 128-cout tiles would leave CUs without a block (256 CUs)
     const long blocks128 = (long)((d.c_out + 127) / 128) * ((a.m_total + 255) / 256);
     if (d.c_out <= 64 || blocks128 < 256) {
-        if (d.c_in == 64 && halo <= 32) return launch_slab_cfg<Slab64r320b1>(a, in, w, bias, out, halo, stream);
-        if (d.c_in == 64 && halo <= 64) return launch_slab_cfg<Slab64r384b1>(a, in, w, bias, out, halo, stream);
+        if (d.c_in == 64 && halo <= 32) return launch_slab_cfg<Slab64r320b1>(a, in, w, bias, out, halo, stream, sgd);
+        if (d.c_in == 64 && halo <= 64) return launch_slab_cfg<Slab64r384b1>(a, in, w, bias, out, halo, stream, sgd);
         static const int t3 = tuning_knob("METRO_SLAB_T3", 1);
-        if (t3 && halo <= 32) return launch_slab_cfg<Slab64r320t3>(a, in, w, bias, out, halo, stream);
-        if (halo <= 32) return launch_slab_cfg<Slab64r320>(a, in, w, bias, out, halo, stream);
-        if (halo <= 64) return launch_slab_cfg<Slab64r384>(a, in, w, bias, out, halo, stream);
-        return launch_slab_cfg<Slab64r512>(a, in, w, bias, out, halo, stream);
+        if (t3 && halo <= 32) return launch_slab_cfg<Slab64r320t3>(a, in, w, bias, out, halo, stream, sgd);
+        if (halo <= 32) return launch_slab_cfg<Slab64r320>(a, in, w, bias, out, halo, stream, sgd);
+        if (halo <= 64) return launch_slab_cfg<Slab64r384>(a, in, w, bias, out, halo, stream, sgd);
+        return launch_slab_cfg<Slab64r512>(a, in, w, bias, out, halo, stream, sgd);
     }
     // 512-pixel tiles (half the weight stream per pixel) once they still give every CU a tile (A/B: 256 beats 512 as the
     // threshold at batch 128 and 256)
     static const int min512 = tuning_knob("METRO_SLAB512_MIN_TILES", 256);
     const long blocks512 = (long)((d.c_out + 127) / 128) * ((a.m_total + 511) / 512);
-    if (blocks512 >= min512) return launch_slab_cfg<Slab128p512>(a, in, w, bias, out, halo, stream);
-    if (halo <= 32) return launch_slab_cfg<Slab128r320>(a, in, w, bias, out, halo, stream);
-    return launch_slab_cfg<Slab128r384>(a, in, w, bias, out, halo, stream);
+    // (sub-grid layers -- strides 4 and 8 -- reach 256 such tiles at 16 / 32 crops, the per-GPU shards of BASELINE.json configs[4] /
+    // [3]; same-box A/B, profiles/r06_ab_subgrid_shards.txt: with 256-pixel tiles the sub-grid order is +1.0 % / +0.2 % SLOWER
+    // than the ring kernel it replaces, with 512-pixel tiles -1.3 % / -0.6 % faster.  METRO_SLAB_SG512_MIN_N raises the batch from
+    // which they may take them: the 32-channel chunks are another fp32 summation order)
+    static const int sg512_min_n = tuning_knob("METRO_SLAB_SG512_MIN_N", 1);
+    if (blocks512 >= min512 && (sgd == 0 || d.n >= sg512_min_n)) return launch_slab_cfg<Slab128p512>(a, in, w, bias, out, halo, stream, sgd);
+    if (halo <= 32) return launch_slab_cfg<Slab128r320>(a, in, w, bias, out, halo, stream, sgd);
+    return launch_slab_cfg<Slab128r384>(a, in, w, bias, out, halo, stream, sgd);
 }
 
 }  // namespace metro

@@ -8,7 +8,7 @@ is `nccl`, gloo in the CPU tests.
 Bits: a shard has the bits of the single-GPU run as long as both run the same kernel instantiations.  In the `f64` parity
 mode that is always the case (one kernel configuration whatever the batch: tests/test_gpu_forward.py,
 test_f64_mode_is_shard_invariant).  In the `f16` throughput mode tile shapes follow the crops per call (thresholds: 128 crops
-at stride 16, 32 at stride 8, 8 at stride 4 -- see inference.estimate_pose), so a shard below a threshold and a full batch above
+at stride 16, 32 at stride 8, 8 at stride 4 for the head, 128 / 32 / 16 for the 3x3 layers -- see inference.estimate_pose), so a shard below a threshold and a full batch above
 it differ by fp16 rounding flips; below the thresholds the bits are the same.
 A failure on ONE rank -- fp16 overflow on its shard, or an exception in its model load / plan build / upload / forward -- is
 made collective: the rank still joins the gather and its status row tells every rank to raise (all_gather_poses_with_status),

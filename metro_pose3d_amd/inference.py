@@ -101,14 +101,15 @@ def estimate_pose(images_tensor, model_path, precision: Optional[str] = None, ch
     more than one rank (one process per GPU), EVERY rank makes this same call with the same N images; rank r computes the
     contiguous shard dist.shard_range(N, r, world) on its own GPU and all ranks return the full [N,Jout,3] after ONE all-gather
     of the poses (RCCL over xGMI under backend `nccl`).  No activation crosses ranks, so the result has the bits of the
-    single-GPU call as long as both run the same kernel instantiations: always below 128 crops per call (see below).
+    single-GPU call as long as both run the same kernel instantiations: at stride 16 always below 128 crops per call (see below).
     `shard=False` keeps the call local; `group` selects a process group.
 
     Results are NOT bit-stable across call sizes: kernel tile shapes follow the crops per call (the engine buckets of 8 / 64 /
-    256; from 128 crops per call on the 3x3 layers take 512-pixel tiles; the head takes 128- and then 256-pixel tiles once it has
-    256 of them: n * S * S / 128 >= 256, i.e. from 128 crops at stride 16, 32 at stride 8, 8 at stride 4) and every tile shape is
-    another fp32 summation order.  Differences are rounding flips of the fp16 chain (tests/test_gpu_forward.py); at stride 16
-    calls below 128 crops agree bit for bit with one another whatever their size.
+    256; the 3x3 layers take 512-pixel tiles once a layer has 256 of them -- from 128 crops per call at stride 16, 32 at stride 8,
+    16 at stride 4; the head takes 128- and then 256-pixel tiles once it has 256 of them: n * S * S / 128 >= 256, i.e. from 128
+    crops at stride 16, 32 at stride 8, 8 at stride 4) and every tile shape is another fp32 summation order.  Differences are
+    rounding flips of the fp16 chain (tests/test_gpu_forward.py); calls below those sizes agree bit for bit with one another
+    whatever their size.
 
     `check_finite` (default on; METRO_CHECK_FINITE=0 turns it off): the finalize launch's non-finite screen is folded on the
     device after every forward of the call and read back ONCE (one stream synchronisation per call, as the reference's blocking

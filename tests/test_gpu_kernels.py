@@ -55,6 +55,13 @@ CONV_CASES = [
     # RN101-s8 block3 conv2 at its per-GPU batch of 32 (rate 2 on 32x32 maps: 64 rows of halo, exactly 256 tiles of 128 cout x
     # 256 px): the 128-cout slab configuration with the 384-row slab (tests/test_kernel_coverage.py runs the full 256 -> 256 shape)
     ('3x3_slab_rate2_32map_r384', 32, 32, 128, 256, 3, 1, 2, 2, 32),
+    # round 6, sub-grid pixel order (conv3x3_f16_slab<...>+subgrid): rates whose plain halo (rate x W rows) exceeds the slab --
+    # rate 4 on 64-wide maps (16 x 16 sub-images), rate 8 on 64-wide maps (8 x 8 sub-images: four per 256-pixel tile), rate 4 on
+    # 32-wide maps (the stride-8 block4 shape), rate 8 on a 16 x 16 map (2 x 2 sub-images: every tap but the centre leaves them)
+    ('3x3_subgrid_rate4_64map', 2, 64, 64, 128, 3, 1, 4, 4, 64),
+    ('3x3_subgrid_rate8_64map', 1, 64, 128, 192, 3, 1, 8, 8, 64),
+    ('3x3_subgrid_rate4_32map', 3, 32, 64, 64, 3, 1, 4, 4, 32),
+    ('3x3_subgrid_rate8_16map', 2, 16, 64, 128, 3, 1, 8, 8, 16),
     # persistent weight-resident 64 -> 64 kernel (conv3x3_c64.hip): blocks walk several 128-pixel tiles (image borders
     # inside a block's range, halo rows shared between consecutive tiles), 64- / 32- / 16-wide maps
     ('3x3_c64_many_tiles', 21, 64, 64, 64, 3, 1, 1, 1, 64),

@@ -360,6 +360,26 @@ def _conv(lib, cuda, li, n, gen, rng, dev, kid, name):
     else:
         check(lib.metro_conv_f16(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr), H.ptr(out), None),
               'metro_conv_f16')
+        if kid.endswith('+subgrid'):
+            # the tap-reuse kernel in sub-grid pixel order against the ring kernel these layers ran on until round 6 (the test
+            # switch puts them back): two correct fp32 summation orders of the same products (chunk-major vs tap-major) --
+            # rounding flips of the fp16 result only
+
+            torch.cuda.synchronize()
+            sub = out.clone()
+            check(lib.metro_conv_b1_form(1), 'metro_conv_b1_form')
+            try:
+                check(lib.metro_conv_f16(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr), H.ptr(out), None),
+                      'metro_conv_f16 (classic form)')
+                torch.cuda.synchronize()
+            finally:
+                lib.metro_conv_b1_form(0)
+            assert _noted(lib)[-1].startswith('conv_igemm_f16_dma<'), _noted(lib)
+            same = (out == sub).float().mean().item()
+            worst = (out.float() - sub.float()).abs().max().item()
+            assert same >= 0.97 and worst <= 2.0 ** -9 * sub.float().abs().max().item(), (kid, same, worst)
+            check(lib.metro_kernel_notes(1), 'metro_kernel_notes')
+            check(lib.metro_conv_f16(C.byref(d), H.ptr(x), H.ptr(tw), H.ptr(tb), H.ptr(ts), H.ptr(tsh), H.ptr(tr), H.ptr(out), None), 'metro_conv_f16')
         if kid.startswith('conv_pws<'):        # the skewed kernel and conv_pw64's lock-step one: the same bits
             torch.cuda.synchronize()
             skewed = out.clone()
