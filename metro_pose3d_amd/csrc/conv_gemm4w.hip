@@ -44,24 +44,30 @@ constexpr int PIECES = 8;                          // 16-byte loads per lane per
 
 __device__ __forceinline__ int g4_swz(int row) { return (row >> 1) & 7; }
 
-template <bool PROLOGUE>
-__global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
-    ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w, const float* __restrict__ bias,
+// NJ: 32-pixel fragments per wave.  4 = the 256 x 256 tile (wave 128 x 128); 2 (round 6) = a 256 cout x 128 pixel HALF tile (wave
+// 128 x 64) for the deep-K layers of batch 64 that have only 128 whole tiles (block4 conv1: 2048 -> 512 on 16 384 pixels; the
+// conv1 part of block4's shortcut + conv1 pair, whose 640 whole tiles were 2.5 rounds on 256 CUs run as three).  Same K order, same bits.
+// tile_m0: first cout tile of this launch (a pair may be launched in two parts).
+// `bid` of `nblk`: this block's index among the blocks of its part of the launch.
+template <bool PROLOGUE, int NJ>
+__device__ __forceinline__ void conv_gemm4w_body(
+    const ConvArgs& a, const half_t* __restrict__ in, const half_t* __restrict__ w, const float* __restrict__ bias,
     const half_t* __restrict__ pro_scale, const half_t* __restrict__ pro_shift, const half_t* __restrict__ residual,
-    half_t* __restrict__ out, half_t* __restrict__ out2, int tiles_m, int mgroups) {
+    half_t* __restrict__ out, half_t* __restrict__ out2, int tiles_m, int mgroups, int tile_m0, int bid, int nblk) {
     using namespace g4;
+    constexpr int TNV = NJ * 64;                       // pixels per tile: 256 or 128
+    constexpr int PB = PIECES * NJ / 4;                // pixel pieces per lane per K tile: 8 or 4
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1;            // 128-cout half
-    const int wc = wave & 1;             // 128-pixel half
+    const int wc = wave & 1;             // pixel half (NJ * 32 pixels)
 
     // XCD-aware (bijective) block -> tile map: the blocks of one XCD share pixel tiles in their L2
-    const int nblk = gridDim.x;
     int lid;
     {
-        const int b = blockIdx.x;
+        const int b = bid;
         const int q = nblk >> 3, r = nblk & 7;
         const int xcd = b & 7, idx = b >> 3;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -72,14 +78,14 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
         // wide outputs (block4's shortcut + conv1 pair: ten cout tiles = 5.2 MB of weights, more than an XCD's 4 MB L2): XCD x
         // owns cout-tile group x % mgroups and pixel-tile set x / mgroups, so its weight working set is 1 / mgroups of the
         // layer and stays L2-resident while each pixel tile is fetched by mgroups XCDs instead of one (host checks divisibility)
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xcd = bid & 7, idx = bid >> 3;
         const int tmg = tiles_m / mgroups, sets = 8 / mgroups;
         const int tns = (nblk / tiles_m) / sets;
         tile_m = (xcd % mgroups) * tmg + idx % tmg;
         tile_n = (xcd / mgroups) * tns + idx / tmg;
     }
-    const int m0 = tile_n * TN;
-    const int n0 = tile_m * TM;
+    const int m0 = tile_n * TNV;
+    const int n0 = (tile_m0 + tile_m) * TM;
     const int K = a.c_in;
     const int nk = K / BK;
     half_t* pro_lds = reinterpret_cast<half_t*>(smem + MAIN_BYTES);
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     // buffer loads: wave-uniform descriptor of the tile's operand rows + ONE per-lane 32-bit offset for both operands (the piece
     // and the K tile go into the scalar offset): no 64-bit address arithmetic in the loop, no address registers
     const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(w + (size_t)n0 * K), 0, 256 * K * 2, 0x00020000);
-    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(in + (size_t)m0 * K), 0, 256 * K * 2, 0x00020000);
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(in + (size_t)m0 * K), 0, TNV * K * 2, 0x00020000);
     const int voff = (srow * K + lch * 8) * 2;
     const int piece_stride = 32 * K * 2;                               // bytes
 
@@ -100,12 +106,14 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
 #define METRO_G4_DEPTH 1     // 2 (a second staged tile, three tiles of lead) measured the same: the loads are not late
 #endif
     constexpr int DEPTH = METRO_G4_DEPTH;                              // staged K tiles in registers: tile k lives in set k % DEPTH
-    u32x4 ra[DEPTH][PIECES], rb[DEPTH][PIECES];
+    u32x4 ra[DEPTH][PIECES], rb[DEPTH][PB];
+    // the pixel piece that travels with weight piece e (-1: none): NJ 4: e; NJ 2: every second weight piece carries one
+    auto bpiece = [](int e) { return NJ == 4 ? e : ((e & 1) == 0 ? e >> 1 : -1); };
     auto load_tile = [&](int set, int kt) {
 #pragma unroll
         for (int e = 0; e < PIECES; ++e) {
             ra[set][e] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, e * piece_stride + kt * BK * 2, 0);
-            rb[set][e] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, e * piece_stride + kt * BK * 2, 0);
+            if (bpiece(e) >= 0) rb[set][bpiece(e)] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, bpiece(e) * piece_stride + kt * BK * 2, 0);
         }
     };
     // pre-activation BN + ReLU on a staged pixel chunk (fp16 FMA, one rounding: resnet_v2.py:119); a lane's chunk is always
@@ -119,34 +127,36 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     };
     auto store_piece = [&](int buf, int set, int e) {
         *reinterpret_cast<u32x4*>(smem + A_OFF + buf * OPER_BYTES + st_off + e * 32 * ROW_BYTES) = ra[set][e];
+        const int eb = bpiece(e);
+        if (eb < 0) return;
         if constexpr (PROLOGUE) {
             const half8_t z = {};
-            half8_t x = *reinterpret_cast<const half8_t*>(&rb[set][e]);
+            half8_t x = *reinterpret_cast<const half8_t*>(&rb[set][eb]);
             x = __builtin_elementwise_max(x * pro_sc + pro_sh, z);
-            *reinterpret_cast<half8_t*>(smem + B_OFF + buf * OPER_BYTES + st_off + e * 32 * ROW_BYTES) = x;
+            *reinterpret_cast<half8_t*>(smem + B_OFF + buf * OPER_BYTES + st_off + eb * 32 * ROW_BYTES) = x;
         } else {
-            *reinterpret_cast<u32x4*>(smem + B_OFF + buf * OPER_BYTES + st_off + e * 32 * ROW_BYTES) = rb[set][e];
+            *reinterpret_cast<u32x4*>(smem + B_OFF + buf * OPER_BYTES + st_off + eb * 32 * ROW_BYTES) = rb[set][eb];
         }
     };
 
-    floatx16 acc[4][4];
+    floatx16 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int frag_row = lane & 31, frag_half = lane >> 5;
-    unsigned a_base[4], b_base[4];       // fragment addresses (buffer 0); k step kk = XOR with kk << 5 on the swizzled chunk bits
+    unsigned a_base[4], b_base[NJ];      // fragment addresses (buffer 0); k step kk = XOR with kk << 5 on the swizzled chunk bits
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = wr * 128 + i * 32 + frag_row;
         a_base[i] = A_OFF + row * ROW_BYTES + ((frag_half ^ g4_swz(row)) << 4);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wc * 128 + j * 32 + frag_row;
+    for (int j = 0; j < NJ; ++j) {
+        const int row = wc * (NJ * 32) + j * 32 + frag_row;
         b_base[j] = B_OFF + row * ROW_BYTES + ((frag_half ^ g4_swz(row)) << 4);
     }
 
@@ -166,10 +176,10 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     if (DEPTH == 2) load_tile(0, nk > 2 ? 2 : nk - 1);
     __syncthreads();
 
-    half8_t af[2][4], bf[2][4];          // two fragment sets: the k step being multiplied and the next one
+    half8_t af[2][4], bf[2][NJ];         // two fragment sets: the k step being multiplied and the next one
     auto load_frags = [&](int set, int buf, int kk) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bf[set][j] = *reinterpret_cast<const half8_t*>(smem + buf * OPER_BYTES + (b_base[j] ^ (kk << 5)));
+        for (int j = 0; j < NJ; ++j) bf[set][j] = *reinterpret_cast<const half8_t*>(smem + buf * OPER_BYTES + (b_base[j] ^ (kk << 5)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[set][i] = *reinterpret_cast<const half8_t*>(smem + buf * OPER_BYTES + (a_base[i] ^ (kk << 5)));
     };
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[set][i], bf[set][j], acc[i][j], 0, 0, 0);
     };
     load_frags(0, 0, 0);
@@ -204,24 +214,41 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
 #pragma unroll
             for (int e = first[kk]; e < first[kk + 1]; ++e) {
                 ra[SET][e] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, e * piece_stride + knext, 0);
-                rb[SET][e] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, e * piece_stride + knext, 0);
+                if (bpiece(e) >= 0) rb[SET][bpiece(e)] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, bpiece(e) * piece_stride + knext, 0);
             }
             mma(kk & 1);
             // emitted order of the step: a fragment read (and the pre-activation VALU of the pieces about to be written) behind each
             // of the first 8 MFMAs, then one LDS write + one request behind each of the next ones
             if (PROLOGUE && kk == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // this tile's scale / shift
+            if constexpr (NJ == 4) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (PROLOGUE) __builtin_amdgcn_sched_group_barrier(0x002, NP, 0);
-            }
+                for (int m = 0; m < 8; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (PROLOGUE) __builtin_amdgcn_sched_group_barrier(0x002, NP, 0);
+                }
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (m < 2 * NP) {
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                for (int m = 0; m < 8; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (m < 2 * NP) {
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+            } else {
+                // half tile: 8 MFMAs per k step carry 6 fragment reads, the pre-activation of <= 2 pixel pieces (8 packed ops each)
+                // and NP weight + NPB pixel pieces written and re-requested: a read, then a write + a request behind every MFMA
+                constexpr int NPB = (first[kk + 1] + 1) / 2 - (first[kk] + 1) / 2;           // even e in [first[kk], first[kk + 1])
+                constexpr int NWR = NP + NPB;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (PROLOGUE && m < 4) __builtin_amdgcn_sched_group_barrier(0x002, 2 * NPB, 0);
+                    if (m >= 8 - NWR) {
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -233,11 +260,11 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
         load_frags(0, BUF ^ 1, 0);
         mma(1);                                  // k step 3: fragments read before the barrier
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < (NJ == 4 ? 8 : 6); ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NJ == 4 ? 8 : 2, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
     for (int t = 0; t < nk; t += 2) {
@@ -259,8 +286,8 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
             const int col = wr * 128 + i * 32 + 8 * q + 4 * frag_half;
             const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + n0 + col);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int prow = wc * 128 + j * 32 + frag_row;
+            for (int j = 0; j < NJ; ++j) {
+                const int prow = wc * (NJ * 32) + j * 32 + frag_row;
                 half4_t hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -274,13 +301,13 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     }
     __syncthreads();
     constexpr int CPRO = TM / 8;                       // 16-byte chunks per tile row
-    constexpr int EPI_ITERS = TN * CPRO / NT;          // 32
+    constexpr int EPI_ITERS = TNV * CPRO / NT;         // 32 (16 for the half tile)
     const bool res_same = a.res_stride == 1 && a.res_offset == 0 && a.res_h == a.h_out && a.res_w == a.w_out;
     const int hw_out = a.h_out * a.w_out;
     // no shortcut to add (every layer this kernel is dispatched for) and a whole 256-channel tile: the chunk reads of eight
     // iterations back to back, then eight full-line stores.  The general loop below carries a per-lane guard and the shortcut
     // branches in every iteration -- hipcc emits read - wait - store 32 times in a row (~2.5 us per 256 x 256 tile).
-    if (residual == nullptr && o_n0 + TM <= o_c && m0 + TN <= a.m_total) {     // block-uniform; m % 256 == 0 is also a host-side precondition
+    if (residual == nullptr && o_n0 + TM <= o_c && m0 + TNV <= a.m_total) {     // block-uniform; m % 256 == 0 is also a host-side precondition
         const int ch = tid & (CPRO - 1), pr0 = tid / CPRO;         // NT % CPRO == 0: a lane keeps its chunk column
 #pragma unroll
         for (int it0 = 0; it0 < EPI_ITERS; it0 += 8) {
@@ -322,8 +349,31 @@ __global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
     }
 }
 
+template <bool PROLOGUE, int NJ>
+__global__ __launch_bounds__(g4::NT) void conv_gemm4w_kernel(
+    ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w, const float* __restrict__ bias,
+    const half_t* __restrict__ pro_scale, const half_t* __restrict__ pro_shift, const half_t* __restrict__ residual,
+    half_t* __restrict__ out, half_t* __restrict__ out2, int tiles_m, int mgroups, int tile_m0) {
+    conv_gemm4w_body<PROLOGUE, NJ>(a, in, w, bias, pro_scale, pro_shift, residual, out, out2, tiles_m, mgroups, tile_m0, blockIdx.x, gridDim.x);
+}
+
+// ONE grid for both parts of a pair: blocks [0, n_whole) = whole tiles of cout tiles [0, tm_whole), the rest = half tiles of cout
+// tiles [tm_whole, tm_whole + tm_half).  The dispatcher hands out blocks in order, so the half tiles fill the CUs the last round
+// of whole tiles leaves idle -- no launch boundary between the parts.  (n_whole % 8 == 0: a block's XCD is blockIdx % 8 in both.)
+template <bool PROLOGUE>
+__global__ __launch_bounds__(g4::NT) void conv_gemm4w_mixed_kernel(
+    ConvArgs a, const half_t* __restrict__ in, const half_t* __restrict__ w, const float* __restrict__ bias,
+    const half_t* __restrict__ pro_scale, const half_t* __restrict__ pro_shift, half_t* __restrict__ out, half_t* __restrict__ out2,
+    int tm_whole, int tm_half, int n_whole) {
+    if ((int)blockIdx.x < n_whole)
+        conv_gemm4w_body<PROLOGUE, 4>(a, in, w, bias, pro_scale, pro_shift, nullptr, out, out2, tm_whole, 1, 0, blockIdx.x, n_whole);
+    else
+        conv_gemm4w_body<PROLOGUE, 2>(a, in, w, bias, pro_scale, pro_shift, nullptr, out, out2, tm_half, 1, tm_whole, blockIdx.x - n_whole,
+                                      gridDim.x - n_whole);
+}
+
 // What the kernel can run: 1x1, stride 1, no padding, dense NHWC fp16 in/out, an even number of 64-channel K tiles,
-// WHOLE 256 x 256 tiles (no zero page here; at stride 16 every image is exactly one 256-pixel tile); a fused pair splits on a
+// WHOLE tiles (no zero page here; at stride 16 every image is exactly one 256-pixel tile); a fused pair splits on a
 // tile boundary and its second output is a whole number of cout tiles (256 = conv1 of block3, 512 = conv1 of block4).
 bool conv_gemm4w_shape_ok(const MetroConvDesc& d, const ConvSplit* split) {
     if (!(d.kh == 1 && d.kw == 1 && d.stride == 1 && d.pad_top == 0 && d.pad_left == 0 && d.in_pix_stride == d.c_in &&
@@ -333,6 +383,15 @@ bool conv_gemm4w_shape_ok(const MetroConvDesc& d, const ConvSplit* split) {
     if (d.c_in % 128 != 0 || d.c_in < 128 || d.c_in > 2048 || d.c_out % 256 != 0 || m % 256 != 0) return false;
     if (split != nullptr && split->split > 0 && (split->split % 256 != 0 || split->c_out2 % 256 != 0 || d.has_residual)) return false;
     return true;
+}
+
+// Half tiles (256 cout x 128 pixels, kernel comment) for `tiles_m` cout tiles of a layer with m pixels: when its whole tiles would
+// leave more than a third of the CUs without work in their last round while the half tiles fill it.  METRO_G4_HALF: 0 = never.
+static bool g4_half_tiles_pay(long tiles_m, long m, int c_in) {
+    static const int enabled = tuning_knob("METRO_G4_HALF", 1);
+    static const int min_k = tuning_knob("METRO_G4_HALF_MIN_K", 1024);
+    const long whole = tiles_m * (m / 256), half = tiles_m * (m / 128);
+    return enabled && c_in >= min_k && m % 128 == 0 && whole < 256 && half >= 224 && half <= 512;
 }
 
 // ... and when the dispatcher prefers it over the ring kernel: a pre-activated layer (every conv1 / projection shortcut / pair
@@ -347,52 +406,87 @@ bool conv_gemm4w_supported(const MetroConvDesc& d, const ConvSplit* split) {
     if (!enabled || !d.has_prologue || !conv_gemm4w_shape_ok(d, split) || d.c_in < min_k) return false;
     const long m = (long)d.n * d.h_out * d.w_out;
     const long tiles = (long)(d.c_out / 256) * (m / 256);
-    return tiles >= min_tiles && (d.c_in >= 1024 || tiles >= 4 * min_tiles);
+    if (tiles >= min_tiles && (d.c_in >= 1024 || tiles >= 4 * min_tiles)) return true;
+    // round 6: one half tile per CU (block4 conv1 at batch 64)
+    return !(split != nullptr && split->split > 0) && g4_half_tiles_pay(d.c_out / 256, m, d.c_in);
 }
 
-int launch_conv_gemm4w(const MetroConvDesc& d, const void* in, const void* w, const float* bias, const void* ps,
-                       const void* pb, const void* res, void* out, hipStream_t stream, const ConvSplit* split) {
+template <bool PRO, int NJ>
+static int launch_g4_part(const ConvArgs& a, const half_t* in, const half_t* w, const float* bias, const half_t* ps, const half_t* pb,
+                          const half_t* r, half_t* out, half_t* out2, int tile_m0, int tiles_m, int mgroups, hipStream_t stream) {
+    auto kern = conv_gemm4w_kernel<PRO, NJ>;
+    constexpr int lds = g4::MAIN_BYTES + (PRO ? g4::PRO_BYTES : 0);
+    static PerDeviceInt done;
+    if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4w")) return st;
+    const int tiles_n = a.m_total / (NJ * 64);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(g4::NT), lds, stream, a, in, w, bias, ps, pb, r, out, out2, tiles_m, mgroups, tile_m0);
+    return launch_status("conv_gemm4w");
+}
+
+int launch_conv_gemm4w(const MetroConvDesc& d, const void* in_, const void* w_, const float* bias, const void* ps_,
+                       const void* pb_, const void* res, void* out_, hipStream_t stream, const ConvSplit* split) {
     if (!conv_gemm4w_shape_ok(d, split)) {
         set_error("conv_gemm4w: needs a 1x1 stride-1 fp16 layer with c_in %% 128 == 0 (<= 2048), c_out %% 256 == 0 and pixels %% 256 == 0 "
                   "(got c_in %d, c_out %d, %d x %d x %d pixels)", d.c_in, d.c_out, d.n, d.h_out, d.w_out);
         return METRO_ERR_UNSUPPORTED;
     }
     ConvArgs a = make_conv_args(d);
-    void* out2 = nullptr;
+    void* out2_ = nullptr;
     if (split != nullptr && split->split > 0) {
         a.split = split->split; a.c_out2 = split->c_out2; a.relu2 = split->relu2;
-        out2 = split->out2;
+        out2_ = split->out2;
     }
-    if (note_kernel("conv_gemm4w<256x256%s>%s%s", d.has_prologue ? ",pro" : "", d.has_residual ? "+res" : "", a.split > 0 ? "+pair" : ""))
-        return METRO_OK;
-    const int tiles_m = (d.c_out + g4::TM - 1) / g4::TM;
-    const int tiles_n = (a.m_total + g4::TN - 1) / g4::TN;
+    const int tiles_m = d.c_out / g4::TM;
+    const int tiles_n = a.m_total / g4::TN;
+    // which part runs on which tile: everything on whole tiles; a lone layer with too few of them on half tiles; a pair whose
+    // FIRST output fills whole rounds of 256 CUs and whose second output does not: the second output's cout tiles on half tiles
+    // in a launch of their own (block4's pair at batch 64: 512 whole tiles + 256 half tiles instead of 640 whole tiles = 2.5 rounds)
+    int tm_whole = tiles_m, tm_half = 0;
+    if (a.split > 0) {
+        const int tm_a = a.split / g4::TM, tm_b = a.c_out2 / g4::TM;
+        if (((long)tm_a * tiles_n) % 256 == 0 && g4_half_tiles_pay(tm_b, a.m_total, d.c_in)) { tm_whole = tm_a; tm_half = tm_b; }
+    } else if ((long)tiles_m * tiles_n < 256 && g4_half_tiles_pay(tiles_m, a.m_total, d.c_in)) {
+        tm_whole = 0; tm_half = tiles_m;
+    }
+    const char* pro_s = d.has_prologue ? ",pro" : "";
+    const char* res_s = d.has_residual ? "+res" : "";
+    const char* pair_s = a.split > 0 ? "+pair" : "";
+    bool dry = false;
+    if (tm_whole > 0) dry = note_kernel("conv_gemm4w<256x256%s>%s%s", pro_s, res_s, pair_s);
+    if (tm_half > 0) dry = note_kernel("conv_gemm4w<256x128%s>%s%s", pro_s, res_s, pair_s) || dry;
+    if (dry) return METRO_OK;
     // cout-tile groups per XCD set (kernel comment): only where the layer's weights exceed an XCD's L2
     static const int mg_knob = tuning_knob("METRO_G4_MGROUPS", 1);
     static const int mg_min_w = tuning_knob("METRO_G4_MGROUPS_MIN_WBYTES", 4 << 20);
     int mgroups = 1;
-    if (mg_knob > 1 && (long)d.c_out * d.c_in * 2 > mg_min_w && 8 % mg_knob == 0 && tiles_m % mg_knob == 0 &&
+    if (tm_half == 0 && mg_knob > 1 && (long)d.c_out * d.c_in * 2 > mg_min_w && 8 % mg_knob == 0 && tiles_m % mg_knob == 0 &&
         tiles_n % (8 / mg_knob) == 0)
         mgroups = mg_knob;
+    const half_t* in = static_cast<const half_t*>(in_);
+    const half_t* w = static_cast<const half_t*>(w_);
+    const half_t* ps = static_cast<const half_t*>(ps_);
+    const half_t* pb = static_cast<const half_t*>(pb_);
     const half_t* r = d.has_residual ? static_cast<const half_t*>(res) : nullptr;
-    if (d.has_prologue) {
-        auto kern = conv_gemm4w_kernel<true>;
+    half_t* out = static_cast<half_t*>(out_);
+    half_t* out2 = static_cast<half_t*>(out2_);
+    static const int mixed = tuning_knob("METRO_G4_MIXED", 1);
+    if (mixed && tm_whole > 0 && tm_half > 0 && r == nullptr && d.has_prologue && ((long)tm_whole * tiles_n) % 8 == 0) {
+        auto kern = conv_gemm4w_mixed_kernel<true>;
         constexpr int lds = g4::MAIN_BYTES + g4::PRO_BYTES;
         static PerDeviceInt done;
-        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4w<pro>")) return st;
-        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(g4::NT), lds, stream, a, static_cast<const half_t*>(in),
-                           static_cast<const half_t*>(w), bias, static_cast<const half_t*>(ps), static_cast<const half_t*>(pb), r,
-                           static_cast<half_t*>(out), static_cast<half_t*>(out2), tiles_m, mgroups);
-    } else {
-        auto kern = conv_gemm4w_kernel<false>;
-        constexpr int lds = g4::MAIN_BYTES;
-        static PerDeviceInt done;
-        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4w")) return st;
-        hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(g4::NT), lds, stream, a, static_cast<const half_t*>(in),
-                           static_cast<const half_t*>(w), bias, nullptr, nullptr, r, static_cast<half_t*>(out),
-                           static_cast<half_t*>(out2), tiles_m, mgroups);
+        if (const int st = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, done, "conv_gemm4w<mixed>")) return st;
+        const int n_whole = tm_whole * tiles_n, n_half = tm_half * (a.m_total / 128);
+        hipLaunchKernelGGL(kern, dim3(n_whole + n_half), dim3(g4::NT), lds, stream, a, in, w, bias, ps, pb, out, out2, tm_whole, tm_half, n_whole);
+        return launch_status("conv_gemm4w<mixed>");
     }
-    return launch_status("conv_gemm4w");
+    int st = METRO_OK;
+    if (tm_whole > 0)
+        st = d.has_prologue ? launch_g4_part<true, 4>(a, in, w, bias, ps, pb, r, out, out2, 0, tm_whole, mgroups, stream)
+                            : launch_g4_part<false, 4>(a, in, w, bias, nullptr, nullptr, r, out, out2, 0, tm_whole, mgroups, stream);
+    if (st == METRO_OK && tm_half > 0)
+        st = d.has_prologue ? launch_g4_part<true, 2>(a, in, w, bias, ps, pb, r, out, out2, tm_whole, tm_half, 1, stream)
+                            : launch_g4_part<false, 2>(a, in, w, bias, nullptr, nullptr, r, out, out2, tm_whole, tm_half, 1, stream);
+    return st;
 }
 
 }  // namespace metro

@@ -571,7 +571,10 @@ def test_error_reporting(lib):
 G8_CASES = [('k128', 2, 128, 256, 'plain'), ('k256_relu', 3, 256, 512, 'relu'), ('k512_pro', 2, 512, 256, 'prologue'),
             ('k1024_pro_relu', 5, 1024, 512, 'prologue+relu'), ('k512_res', 3, 512, 768, 'residual'),
             ('k2048_pro', 2, 2048, 256, 'prologue'), ('pair_k512', 3, 512, 1280, 'pair'), ('pair_k256', 2, 256, 512, 'pair'),
-            ('pair512_k1024', 2, 1024, 2560, 'pair512')]        # block4/unit_1: shortcut 2048 + conv1 512 (gemm4w only)
+            ('pair512_k1024', 2, 1024, 2560, 'pair512'),        # block4/unit_1: shortcut 2048 + conv1 512 (gemm4w only)
+            # round 6, the batch-64 shapes of block4: 128 whole tiles -> 256 HALF tiles (256 cout x 128 px) in conv_gemm4w; the pair as
+            # 512 whole + 256 half tiles in one grid (the other kernels run their own tiling of the same shape: same bits)
+            ('k2048_pro_half_tiles', 64, 2048, 512, 'prologue'), ('pair512_k1024_mixed_tiles', 64, 1024, 2560, 'pair512')]
 
 
 @pytest.mark.parametrize('case', G8_CASES, ids=[c[0] for c in G8_CASES])
