@@ -685,7 +685,6 @@ static int launch_dma_cfg(const ConvArgs& a, const half_t* in, const half_t* w, 
 //                        WAVES_M WAVES_N WM WN STAGES BK   tile (cout x pixels), waves, LDS
 using Dma128x256s3 = DmaCfg<2, 4, 2, 2, 3>;        // 128 x 256, 8 waves, 144 KiB: deep-K, >= 256 tiles
 using Dma128x128s4 = DmaCfg<2, 4, 2, 1, 4>;        // 128 x 128, 8 waves, 128 KiB: deep-K, few tiles
-using Dma256x128s3 = DmaCfg<4, 2, 2, 2, 3>;        // 256 x 128, 8 waves, 144 KiB: deep-K, exactly one tile per CU (round 6, below)
 using Dma128x128s2 = DmaCfg<2, 4, 2, 1, 2>;        // 128 x 128, 8 waves,  64 KiB: 2 blocks / CU
 using Dma128x128s1 = DmaCfg<2, 4, 2, 1, 1>;        // 128 x 128, 8 waves,  34 KiB: 3 blocks / CU (K <= 64)
 using Dma256x256s4k32 = DmaCfg<2, 4, 4, 2, 4, 32>; // same tile, BK 32, 4 stages
@@ -804,17 +803,6 @@ int launch_conv_f16_dma(const MetroConvDesc& d, const void* in_, const void* w_,
     const long blocks256 = (long)tiles128 * ((a.m_total + 255) / 256);
     static const int big = env_int("METRO_DMA_BIG", 2);
     if (big && d.c_out % 256 == 0 && blocks256 / 2 >= 256) { METRO_DMA(Dma256x256s4k32); }
-    // Deep-K layers with about ONE tile per CU (block4 conv1 at batch 64: 2048 -> 512 on 16 384 pixels): the transposed tile,
-    // 256 cout x 128 pixels.  A CU streams (TM + TN) x K x 2 bytes either way, but the PIXEL rows are first-touch (Infinity
-    // Cache / HBM latency: the cout tiles of a pixel tile run in lock step on one XCD, nobody runs ahead to warm the L2) while
-    // the WEIGHT rows are L2 hits shared by every block of the XCD: halving the pixel rows per CU trades slow bytes for fast
-    // ones.  Same K order, same bits.  METRO_DMA_WIDE_MIN_K: 0 = off.
-    static const int wide_min_k = env_int("METRO_DMA_WIDE_MIN_K", 0);
-    {
-        const long blocks_w = (long)(d.c_out / 256) * ((a.m_total + 127) / 128);
-        if (wide_min_k > 0 && d.kh == 1 && d.kw == 1 && d.c_in >= wide_min_k && d.c_out % 256 == 0 && a.split == 0 &&
-            blocks_w >= 224 && blocks_w <= 512) { METRO_DMA(Dma256x128s3); }
-    }
     if (blocks256 >= 256) { METRO_DMA(Dma128x256s3); }
     // deep-K layers whose 128 x 128 tiles leave CUs idle (block2/unit_4's strided 3x3 at batch 64: 128 tiles on 256 CUs): 64-cout
     // tiles double the blocks (same pixel gather per block, half the weight rows and MFMAs per K step); same bits
