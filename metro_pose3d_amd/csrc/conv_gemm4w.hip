@@ -55,8 +55,8 @@ __device__ __forceinline__ void conv_gemm4w_body(
     const half_t* __restrict__ pro_scale, const half_t* __restrict__ pro_shift, const half_t* __restrict__ residual,
     half_t* __restrict__ out, half_t* __restrict__ out2, int tiles_m, int mgroups, int tile_m0, int bid, int nblk) {
     using namespace g4;
-    constexpr int TNV = NJ * 64;                       // pixels per tile: 256 or 128
-    constexpr int PB = PIECES * NJ / 4;                // pixel pieces per lane per K tile: 8 or 4
+    constexpr int TNV = NJ * 64;                       // pixels per tile: 256, 128 or (NJ 1: a QUARTER tile, wave 128 x 32) 64
+    constexpr int PB = PIECES * NJ / 4;                // pixel pieces per lane per K tile: 8, 4 or 2
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -108,7 +108,7 @@ __device__ __forceinline__ void conv_gemm4w_body(
     constexpr int DEPTH = METRO_G4_DEPTH;                              // staged K tiles in registers: tile k lives in set k % DEPTH
     u32x4 ra[DEPTH][PIECES], rb[DEPTH][PB];
     // the pixel piece that travels with weight piece e (-1: none): NJ 4: e; NJ 2: every second weight piece carries one
-    auto bpiece = [](int e) { return NJ == 4 ? e : ((e & 1) == 0 ? e >> 1 : -1); };
+    auto bpiece = [](int e) { return NJ == 4 ? e : (e % (4 / NJ) == 0 ? e / (4 / NJ) : -1); };
     auto load_tile = [&](int set, int kt) {
 #pragma unroll
         for (int e = 0; e < PIECES; ++e) {
@@ -238,16 +238,21 @@ __device__ __forceinline__ void conv_gemm4w_body(
             } else {
                 // half tile: 8 MFMAs per k step carry 6 fragment reads, the pre-activation of <= 2 pixel pieces (8 packed ops each)
                 // and NP weight + NPB pixel pieces written and re-requested: a read, then a write + a request behind every MFMA
-                constexpr int NPB = (first[kk + 1] + 1) / 2 - (first[kk] + 1) / 2;           // even e in [first[kk], first[kk + 1])
+                // (quarter tile: 4 MFMAs per k step, 5 reads, <= 4 writes + requests: two of each behind every MFMA)
+                constexpr int STR = 4 / NJ;                                                  // every STR-th weight piece carries a pixel piece
+                constexpr int NPB = (first[kk + 1] + STR - 1) / STR - (first[kk] + STR - 1) / STR;
                 constexpr int NWR = NP + NPB;
+                constexpr int NM = 4 * NJ, NRD = 4 + NJ;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
+                for (int m = 0; m < NM; ++m) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if (PROLOGUE && m < 4) __builtin_amdgcn_sched_group_barrier(0x002, 2 * NPB, 0);
-                    if (m >= 8 - NWR) {
-                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (NJ == 1 && m == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // quarter tile: 5 reads behind 4 MFMAs
+                    if (m < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (PROLOGUE && NPB > 0) __builtin_amdgcn_sched_group_barrier(0x002, 8 * NPB / NM, 0);
+                    if (NJ == 2 ? m >= NM - NWR : true) {
+                        constexpr int PER = NJ == 2 ? 1 : (NWR + NM - 1) / NM;
+                        __builtin_amdgcn_sched_group_barrier(0x200, PER, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, PER, 0);
                     }
                 }
             }
@@ -260,11 +265,12 @@ __device__ __forceinline__ void conv_gemm4w_body(
         load_frags(0, BUF ^ 1, 0);
         mma(1);                                  // k step 3: fragments read before the barrier
 #pragma unroll
-        for (int m = 0; m < (NJ == 4 ? 8 : 6); ++m) {
+        for (int m = 0; m < (NJ == 4 ? 8 : NJ == 2 ? 6 : 4); ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (NJ == 1 && m == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, NJ == 4 ? 8 : 2, 0);
+        if (NJ != 1) __builtin_amdgcn_sched_group_barrier(0x008, NJ == 4 ? 8 : 2, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
     for (int t = 0; t < nk; t += 2) {
@@ -387,6 +393,17 @@ bool conv_gemm4w_shape_ok(const MetroConvDesc& d, const ConvSplit* split) {
 
 // Half tiles (256 cout x 128 pixels, kernel comment) for `tiles_m` cout tiles of a layer with m pixels: when its whole tiles would
 // leave more than a third of the CUs without work in their last round while the half tiles fill it.  METRO_G4_HALF: 0 = never.
+// ... and QUARTER tiles (256 cout x 64 pixels) where even the half tiles leave half of the CUs idle.  Measured (same-box A/B,
+// profiles/r06_ab_gemm4w_quarter_tiles.txt): block4's conv1 at batch 32 (2048 -> 512 on 8 192 pixels) -0.5 % of that step; block3's
+// conv1 at batch 64 (1024 -> 256 on 16 384 pixels: 64 whole / 128 half / 256 quarter tiles) the same as the ring kernel's 128 x 128
+// tiles (22.1 vs 22.2 us) -- hence K >= 2048.  METRO_G4_QUARTER: 0 = never.
+static bool g4_quarter_tiles_pay(long tiles_m, long m, int c_in) {
+    static const int enabled = tuning_knob("METRO_G4_QUARTER", 1);
+    static const int min_k = tuning_knob("METRO_G4_QUARTER_MIN_K", 2048);
+    const long half = tiles_m * (m / 128), quarter = tiles_m * (m / 64);
+    return enabled && c_in >= min_k && m % 64 == 0 && half < 224 && quarter >= 224 && quarter <= 512;
+}
+
 static bool g4_half_tiles_pay(long tiles_m, long m, int c_in) {
     static const int enabled = tuning_knob("METRO_G4_HALF", 1);
     static const int min_k = tuning_knob("METRO_G4_HALF_MIN_K", 1024);
@@ -407,8 +424,8 @@ bool conv_gemm4w_supported(const MetroConvDesc& d, const ConvSplit* split) {
     const long m = (long)d.n * d.h_out * d.w_out;
     const long tiles = (long)(d.c_out / 256) * (m / 256);
     if (tiles >= min_tiles && (d.c_in >= 1024 || tiles >= 4 * min_tiles)) return true;
-    // round 6: one half tile per CU (block4 conv1 at batch 64)
-    return !(split != nullptr && split->split > 0) && g4_half_tiles_pay(d.c_out / 256, m, d.c_in);
+    // round 6: one half / quarter tile per CU (block4 / block3 conv1 at batch 64)
+    return !(split != nullptr && split->split > 0) && (g4_half_tiles_pay(d.c_out / 256, m, d.c_in) || g4_quarter_tiles_pay(d.c_out / 256, m, d.c_in));
 }
 
 template <bool PRO, int NJ>
@@ -447,6 +464,13 @@ int launch_conv_gemm4w(const MetroConvDesc& d, const void* in_, const void* w_, 
         if (((long)tm_a * tiles_n) % 256 == 0 && g4_half_tiles_pay(tm_b, a.m_total, d.c_in)) { tm_whole = tm_a; tm_half = tm_b; }
     } else if ((long)tiles_m * tiles_n < 256 && g4_half_tiles_pay(tiles_m, a.m_total, d.c_in)) {
         tm_whole = 0; tm_half = tiles_m;
+    } else if ((long)tiles_m * tiles_n < 256 && g4_quarter_tiles_pay(tiles_m, a.m_total, d.c_in)) {
+        if (note_kernel("conv_gemm4w<256x64%s>%s", d.has_prologue ? ",pro" : "", d.has_residual ? "+res" : "")) return METRO_OK;
+        const half_t* rq = d.has_residual ? static_cast<const half_t*>(res) : nullptr;
+        return d.has_prologue ? launch_g4_part<true, 1>(a, static_cast<const half_t*>(in_), static_cast<const half_t*>(w_), bias, static_cast<const half_t*>(ps_),
+                                                        static_cast<const half_t*>(pb_), rq, static_cast<half_t*>(out_), nullptr, 0, tiles_m, 1, stream)
+                              : launch_g4_part<false, 1>(a, static_cast<const half_t*>(in_), static_cast<const half_t*>(w_), bias, nullptr, nullptr, rq,
+                                                         static_cast<half_t*>(out_), nullptr, 0, tiles_m, 1, stream);
     }
     const char* pro_s = d.has_prologue ? ",pro" : "";
     const char* res_s = d.has_residual ? "+res" : "";

@@ -38,6 +38,8 @@ CONFIGS = {
     # statistics path: five-joint batches are for depth 8) and 128-pixel tiles with 144 weight rows (17 joints at stride 8)
     'X-rn50-s16-J17-D4-b64': (ModelSpec(50, 16, 'h36m', depth=4), 64),
     'X-rn50-s8-J17-b32': (ModelSpec(50, 8, 'h36m'), 32),
+    # estimate_pose's middle bucket: block4's conv1 on conv_gemm4w QUARTER tiles (256 cout x 64 px, round 6), block4's pair at 1.25 rounds
+    'X-rn50-s16-J17-b32': (ModelSpec(50, 16, 'h36m'), 32),
     # the released `many_*` exports: the 53-joint `merged` head = 424 channels (reference data/datasets.py:142-154, main.py:119-127)
     # in three joint groups on the ring head (round 5), 64- and 128-pixel tiles
     'X-rn50-s16-merged53-b64': (ModelSpec(50, 16, 'merged'), 64),
