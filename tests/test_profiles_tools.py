@@ -55,7 +55,7 @@ def test_floors_of_the_default_table_use_batch64_flops():
     assert abs(float(total[2]) - 15.299 * 64) < 1.0, total
 
 
-@pytest.mark.parametrize('name', ['knockouts_r02_r04.patch', 'knockouts_r05.patch'])
+@pytest.mark.parametrize('name', ['knockouts_r02_r04.patch', 'knockouts_r05.patch', 'knockouts_r06.patch'])
 def test_knockout_patches_still_apply(name):
     """The timing knock-outs (#ifdef METRO_DBG_*) live OUTSIDE the product kernels, as patches (tools/build_dbg_variants.sh): they
     must keep applying to the sources they instrument, or the knock-out tables of NOTES_dead_ends.md stop being reproducible."""
