@@ -287,6 +287,11 @@ int  metro_conv_b1_form(int32_t classic);
  * 1x1, stride 1, c_in % 128 == 0, c_out % 256 == 0, n*h*w % 256 == 0.  split > 0: fused pair (rows [0,split) ->
  * d_out, rows [split, c_out) with ReLU -> d_out2, (c_out - split) % 256 == 0); split == 0: plain layer, d_out2 ignored.
  * Same K order and one fp32 accumulator per output as every other fp16 conv kernel here: bit-identical to them.
+ * Round 6: the entry picks the tile itself, as metro_forward does -- whole 256 x 256 tiles; HALF tiles (256 cout x 128 pixels) for
+ * a layer with fewer than 256 whole but >= 224 half tiles and K >= 1024 (block4's conv1 at 64 crops); QUARTER tiles (256 x 64) for
+ * K >= 2048 below that (32 crops); a pair whose first output fills whole rounds of 256 CUs while its second one has < 256 whole
+ * tiles as whole + half tiles in one grid (block4's pair at 64 crops).  metro_last_kernel_id names the forms
+ * ("conv_gemm4w<256x128,pro>", "...<256x256,pro>+pair & ...<256x128,pro>+pair").  Same bits whatever the tile.
  * (Two earlier forms of this GEMM that metro_forward never dispatches -- conv_gemm8p, conv_gemm4d -- are built into
  * libmetro_experimental.so: metro_pose3d_amd/csrc/experimental/metro_experimental.h.) */
 int  metro_conv_f16_gemm4w(const MetroConvDesc* d, const void* d_in, const void* d_w, const float* d_bias,
