@@ -83,6 +83,19 @@ def test_every_layer_names_its_kernel_without_a_gpu():
     assert ids['C4-rn101-s8-J19-b32']['block3/unit_2/conv2'] == 'conv3x3_f16_slab<128x256,rows384,bufs2,tps1,kc64,ws3>'
     small = {li.name.decode(): kid for _, li, kid in dispatch_table(ModelSpec(101, 8, 'many19'), 1)}
     assert small['block3/unit_2/conv2'] != ids['C4-rn101-s8-J19-b32']['block3/unit_2/conv2']
+    # round 6: the rate-4 / rate-8 3x3 layers of strides 4 and 8 run on the tap-reuse kernel in sub-grid pixel order (they fell to the ring kernel
+    # before); block4's conv1 at 64 crops on conv_gemm4w HALF tiles, its shortcut + conv1 pair as whole + half tiles in one grid; at 32 crops
+    # QUARTER tiles; RN101-s8's block3 conv1 at 32 crops on half tiles
+    assert ids['C5-rn50-s4-J17-b16']['block4/unit_2/conv2'] == 'conv3x3_f16_slab<128x512,rows640,bufs2,tps1,kc32,ws4>+subgrid'
+    assert ids['C5-rn50-s4-J17-b16']['block3/unit_2/conv2'].endswith('+subgrid') and ids['C4-rn101-s8-J19-b32']['block4/unit_2/conv2'].endswith('+subgrid')
+    assert not any(k.startswith('conv_igemm_f16_dma') for n_, k in ids['C5-rn50-s4-J17-b16'].items() if n_.endswith('/conv2') and ('block3' in n_ or 'block4' in n_))
+    assert '+subgrid' not in ids['C2-rn50-s16-J17-b64']['block4/unit_2/conv2']        # rate 2 on 16 x 16: the plain order (measured faster)
+    assert ids['C2-rn50-s16-J17-b64']['block4/unit_2/conv1'] == 'conv_gemm4w<256x128,pro>'
+    assert ids['C2-rn50-s16-J17-b64']['block4/unit_1/shortcut+conv1'] == 'conv_gemm4w<256x256,pro>+pair & conv_gemm4w<256x128,pro>+pair'
+    assert ids['C2-rn50-s16-J17-b256']['block4/unit_2/conv1'] == 'conv_gemm4w<256x256,pro>'
+    assert ids['C2-rn50-s16-J17-b256']['block4/unit_1/shortcut+conv1'] == 'conv_gemm4w<256x256,pro>+pair'
+    assert ids['X-rn50-s16-J17-b32']['block4/unit_2/conv1'] == 'conv_gemm4w<256x64,pro>'
+    assert ids['C4-rn101-s8-J19-b32']['block3/unit_2/conv1'] == 'conv_gemm4w<256x128,pro>'
     # the one-launch head and its finalize
     # (head_f16.hip: tile width by the number of tiles, weight rows by the head's channels, K-parts per wave group)
     assert ids['C1-rn50-s32-J17-b1']['logits'] == ids['C2-rn50-s16-J17-b64']['logits'] == 'head_f16<144x64,k4>'
