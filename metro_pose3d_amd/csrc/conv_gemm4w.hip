@@ -43,6 +43,8 @@ constexpr int PIECES = 8;                          // 16-byte loads per lane per
 }  // namespace g4
 
 __device__ __forceinline__ int g4_swz(int row) { return (row >> 1) & 7; }
+typedef float g4_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int g4_u32x2 __attribute__((ext_vector_type(2)));
 
 // NJ: 32-pixel fragments per wave.  4 = the 256 x 256 tile (wave 128 x 128); 2 (round 6) = a 256 cout x 128 pixel HALF tile (wave
 // 128 x 64) for the deep-K layers of batch 64 that have only 128 whole tiles (block4 conv1: 2048 -> 512 on 16 384 pixels; the
@@ -285,26 +287,44 @@ __device__ __forceinline__ void conv_gemm4w_body(
     const int o_n0 = second ? n0 - a.split : n0;
     const int o_relu = second ? a.relu2 : a.relu;
     half_t* o_ptr = second ? out2 : out;
+    // 256 accumulators per lane leave through ~1 150 VALU operations when written element by element (accvgpr_read, add, max + select
+    // for the run-time ReLU flag, convert): 7 000 - 7 800 cycles of the tile's 12 000-cycle epilogue with one wave per SIMD
+    // (tools/gemm4w_clock.py).  Here: the 16 bias quads fetched up front, packed fp32 adds, v_cvt_pk_f16_f32 (round to nearest even, as
+    // the (half_t) casts), and the ReLU on the packed fp16 result -- max(fp16(v), 0) == fp16(max(v, 0)): rounding is monotonic and keeps
+    // the sign -- under a block-uniform branch.  Same bits.
+    floatx4 bvq[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int col = wr * 128 + i * 32 + 8 * q + 4 * frag_half;
-            const floatx4 bv = *reinterpret_cast<const floatx4*>(bias + n0 + col);
+        for (int q = 0; q < 4; ++q) bvq[i][q] = *reinterpret_cast<const floatx4*>(bias + n0 + wr * 128 + i * 32 + 8 * q + 4 * frag_half);
+    auto write_tile = [&](auto relu_c) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int prow = wc * (NJ * 32) + j * 32 + frag_row;
-                half4_t hv;
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[i][j][4 * q + e] + bv[e];
-                    if (o_relu) v = fmaxf(v, 0.f);
-                    hv[e] = (half_t)v;
+            for (int q = 0; q < 4; ++q) {
+                const int col = wr * 128 + i * 32 + 8 * q + 4 * frag_half;
+                const g4_f32x2 blo = {bvq[i][q][0], bvq[i][q][1]}, bhi = {bvq[i][q][2], bvq[i][q][3]};
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int prow = wc * (NJ * 32) + j * 32 + frag_row;
+                    g4_f32x2 lo = {acc[i][j][4 * q], acc[i][j][4 * q + 1]}, hi = {acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(lo), "v"(blo));
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(bhi));
+                    g4_u32x2 r;
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r.x) : "v"(lo.x), "v"(lo.y));
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r.y) : "v"(hi.x), "v"(hi.y));
+                    half4_t hv = __builtin_bit_cast(half4_t, r);
+                    if constexpr (decltype(relu_c)::value) {
+                        const half4_t z = {};
+                        hv = __builtin_elementwise_max(hv, z);
+                    }
+                    *reinterpret_cast<half4_t*>(smem + prow * OUT_ROW_BYTES + col * 2) = hv;
                 }
-                *reinterpret_cast<half4_t*>(smem + prow * OUT_ROW_BYTES + col * 2) = hv;
             }
         }
-    }
+    };
+    if (o_relu) write_tile(std::true_type{});
+    else write_tile(std::false_type{});
     __syncthreads();
     constexpr int CPRO = TM / 8;                       // 16-byte chunks per tile row
     constexpr int EPI_ITERS = TNV * CPRO / NT;         // 32 (16 for the half tile)
