@@ -189,7 +189,7 @@ def estimate_pose(images_tensor, model_path, precision: Optional[str] = None, ch
     if err is not None:
         raise err
     if any(st != 0 for st in statuses):
-        failed = ', '.join(f'rank {r}: ' + ('forward raised' if st < 0 else f'{st} crops') for r, st in enumerate(statuses) if st != 0)
+        failed = ', '.join(f'rank {r}: ' + ('raised (model load, plan build, upload or forward)' if st < 0 else f'{st} crops') for r, st in enumerate(statuses) if st != 0)
         if any(st < 0 for st in statuses):
             raise _lib.MetroError(f'estimate_pose failed on another rank ({failed}); no poses returned on any rank')
         raise _lib.NonFiniteError(

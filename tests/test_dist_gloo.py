@@ -163,10 +163,23 @@ def _failing_rank_worker(rank, world, port, n, mode, q):
         eng = _FakeEngine(64, bad_crops=2 if (mode == 'overflow' and rank == 1) else 0,
                           raise_in_forward=(mode == 'raise' and rank == 1))
         INF._engine_for = lambda model_path, precision, device, n_call=64: eng
+        model_path = 'unused.npz'
+        if mode == 'engine':
+            # round 6: rank 1 fails BEFORE the forward loop -- plan build / workspace allocation inside _engine_for.  It
+            # still joins the gather: the output joint count comes from the model file, which it can read
+            import tempfile
+            from metro_pose3d_amd import ModelSpec, save_model, synth
+            spec = ModelSpec(50, 32, 'h36m', base_width=8)
+            model_path = os.path.join(tempfile.mkdtemp(prefix=f'metro_gloo_{rank}_'), 'toy.npz')
+            save_model(model_path, spec, synth.make_params(spec.arch, spec.n_head_channels, spec.base_width, seed=0))
+            if rank == 1:
+                def failing(model_path, precision, device, n_call=64):
+                    raise RuntimeError('stand-in plan failure on this rank')
+                INF._engine_for = failing
         INF._resolve_device = lambda t: torch.device('cpu')
         images = torch.rand((n, 256, 256, 3), generator=torch.Generator().manual_seed(3))
         try:
-            INF.estimate_pose(images, 'unused.npz')
+            INF.estimate_pose(images, model_path)
             q.put((rank, 'returned', ''))
         except _lib.NonFiniteError as e:
             q.put((rank, 'nonfinite', str(e)))
@@ -182,7 +195,7 @@ def _failing_rank_worker(rank, world, port, n, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('mode', ['overflow', 'raise'])
+@pytest.mark.parametrize('mode', ['overflow', 'raise', 'engine'])
 def test_a_failure_on_one_rank_raises_on_every_rank_instead_of_hanging(mode):
     """rank 1's shard overflows fp16 / its forward raises.  Every rank must still join the one gather and
     then raise -- the healthy rank may not block in all_gather_into_tensor until the watchdog fires."""
@@ -203,6 +216,9 @@ def test_a_failure_on_one_rank_raises_on_every_rank_instead_of_hanging(mode):
     if mode == 'overflow':
         assert outcome[0][0] == outcome[1][0] == 'nonfinite'
         assert 'rank 1: 2 crops' in outcome[0][1] and 'f32m' in outcome[0][1]
+    elif mode == 'engine':
+        assert outcome[1] == ('runtime', 'stand-in plan failure on this rank')
+        assert outcome[0][0] == 'metro' and 'rank 1: raised' in outcome[0][1]
     else:
         assert outcome[1] == ('runtime', 'stand-in HIP failure on this rank')       # the failing rank re-raises its own error
-        assert outcome[0][0] == 'metro' and 'rank 1: forward raised' in outcome[0][1]
+        assert outcome[0][0] == 'metro' and 'rank 1: raised' in outcome[0][1]
